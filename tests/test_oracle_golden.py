@@ -1,0 +1,138 @@
+"""The CPU oracle against the golden vectors emitted by the reference's own source
+(tests/tools/make_golden.py) and against the first-principles dense oracle."""
+import numpy as np
+import pytest
+
+from oracle import metmhn_oracle as O
+from oracle import dense as D
+
+TOL = dict(rtol=1e-10, atol=1e-12)
+
+
+def _cases(g):
+    return range(int(g["n_cases"]))
+
+
+def test_primitives(golden):
+    g = golden("primitives")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"]
+        st, p, x = g[pre + "state"], g[pre + "p"], g[pre + "x"]
+        k = int(st.sum())
+        for dg in (0, 1):
+            for tr in (0, 1):
+                np.testing.assert_allclose(O.kronvec(lt, p, st, bool(dg), bool(tr)), g[pre + f"kv_d{dg}_t{tr}"], **TOL)
+        np.testing.assert_allclose(O.kron_diag(lt, st, k), g[pre + "kron_diag"], **TOL)
+        if st[-1] == 1:
+            np.testing.assert_allclose(O.diag_scal_p(dp, st, p), g[pre + "dsp"], **TOL)
+            np.testing.assert_allclose(O.diag_scal_m(dm, st, p), g[pre + "dsm"], **TOL)
+            n_prim, n_met = int(st[::2].sum()), int(st[1::2].sum() + 1)
+            for name, pf, ns in (("pf", True, n_met), ("mf", False, n_prim)):
+                assert np.array_equal(O.obs_states(k, st, pf), g[pre + "obs_" + name])
+                assert np.array_equal(O.obs_indices(k, st, pf, ns), g[pre + "idx_" + name])   # bit-exact
+            if k >= 2:
+                for tr in (0, 1):
+                    np.testing.assert_allclose(O.R_i_inv_vec(lt, dp, dm, x, st, k, bool(tr)), g[pre + f"R_t{tr}"], **TOL)
+                np.testing.assert_allclose(O.x_partial_Q_y(lt, x, p, st), g[pre + "xQy"], **TOL)
+                a, b = O.x_partial_D_y(dm, dp, st, x, p)
+                np.testing.assert_allclose(a, g[pre + "xDy_dp"], **TOL)
+                np.testing.assert_allclose(b, g[pre + "xDy_dm"], **TOL)
+
+
+def test_vanilla(golden):
+    g = golden("vanilla")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"]
+        st, p, x, dr = g[pre + "state"], g[pre + "p"], g[pre + "x"], g[pre + "d_rates"]
+        for dg in (0, 1):
+            for tr in (0, 1):
+                np.testing.assert_allclose(O.v_kronvec(lt, p, st, bool(dg), bool(tr)), g[pre + f"kv_d{dg}_t{tr}"], **TOL)
+        np.testing.assert_allclose(O.v_kron_diag(lt, st, np.ones_like(p)), g[pre + "kron_diag"], **TOL)
+        for tr in (0, 1):
+            np.testing.assert_allclose(O.v_R_inv_vec(lt, x, st, 1.0, bool(tr)), g[pre + f"R1_t{tr}"], **TOL)
+            np.testing.assert_allclose(O.v_R_inv_vec(lt, x, st, dr, bool(tr)), g[pre + f"Rd_t{tr}"], **TOL)
+        a, b = O.v_x_partial_Q_y(lt, x, p, st)
+        np.testing.assert_allclose(a, g[pre + "xQy"], **TOL)
+        np.testing.assert_allclose(b, g[pre + "xQy_ddiag"], **TOL)
+        a, b, c_ = O.v_gradient(lt, st, g[pre + "p0"])
+        np.testing.assert_allclose(a, g[pre + "grad_th"], **TOL)
+        np.testing.assert_allclose(b, g[pre + "grad_ddiag"], **TOL)
+        np.testing.assert_allclose(c_, g[pre + "grad_pth"], **TOL)
+        if st[-1] == 1:
+            a, b = O.v_scal_d_pt(dp, dm, st, p)
+            np.testing.assert_allclose(a, g[pre + "scal_dp"], **TOL)
+            np.testing.assert_allclose(b, g[pre + "scal_dm"], **TOL)
+            a, b = O.v_x_partial_D_y(dp, dm, st, x, p)
+            np.testing.assert_allclose(a, g[pre + "xDy_dp"], **TOL)
+            np.testing.assert_allclose(b, g[pre + "xDy_dm"], **TOL)
+
+
+def test_patients(golden):
+    g = golden("patients")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        for r, row in enumerate(dat):
+            lp, is0 = O.patient_lp(lt, dp, dm, row)
+            np.testing.assert_allclose(lp, g[pre + "lp_score"][r], **TOL)
+            lp2, gth, gdp, gdm, _ = O.patient_grad(lt, dp, dm, row)
+            np.testing.assert_allclose(lp2, g[pre + "lp_grad"][r], **TOL)
+            np.testing.assert_allclose(gth, g[pre + "d_th"][r], **TOL)
+            np.testing.assert_allclose(gdp, g[pre + "d_dp"][r], **TOL)
+            np.testing.assert_allclose(gdm, g[pre + "d_dm"][r], **TOL)
+            # independent dense oracle on the log-probability
+            np.testing.assert_allclose(D.patient_lp(lt, dp, dm, row), lp, rtol=1e-9)
+
+
+def test_cohorts(golden):
+    g = golden("cohorts")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        pm, lam = float(g[pre + "perc_met"]), float(g[pre + "lam"])
+        s, gth, gdp, gdm = O.score_and_grad(lt, dp, dm, dat, pm)
+        np.testing.assert_allclose(s, g[pre + "score"], **TOL)
+        np.testing.assert_allclose(O.score(lt, dp, dm, dat, pm), g[pre + "score_only"], **TOL)
+        np.testing.assert_allclose(gth, g[pre + "d_th"], **TOL)
+        np.testing.assert_allclose(gdp, g[pre + "d_dp"], **TOL)
+        np.testing.assert_allclose(gdm, g[pre + "d_dm"], **TOL)
+        params = np.concatenate((lt.flatten(), dp, dm))
+        v, gr = O.score_and_grad_reg(params, dat, pm, O.symmetric_penal, lam)
+        np.testing.assert_allclose(v, g[pre + "reg_value"], **TOL)
+        np.testing.assert_allclose(gr, g[pre + "reg_grad"], **TOL)
+        np.testing.assert_allclose(O.score_reg(params, dat, pm, O.symmetric_penal, lam), g[pre + "reg_value_only"], **TOL)
+        pen, pen_ = O.symmetric_penal(params, lt.shape[0])
+        np.testing.assert_allclose(pen, g[pre + "pen"], **TOL)
+        np.testing.assert_allclose(pen_, g[pre + "pen_grad"], **TOL)
+
+
+def test_survey_anchor_c1(golden):
+    """SURVEY.md Appendix C.1 known-answer values."""
+    g = golden("cohorts")
+    assert abs(float(g["c0_score"]) - (-5.3401612761381285)) < 1e-13
+    assert abs(float(g["c0_reg_value"]) - 9.25186325475162) < 1e-12
+    assert abs(np.linalg.norm(g["c0_reg_grad"]) - 2.1596327054018287) < 1e-12
+
+
+def test_gradient_is_fd_of_score():
+    """Property the reference's tests/test_gradient.py pins: analytic gradient == forward FD of score."""
+    rng = np.random.default_rng(3)
+    n = 3
+    lt = rng.normal(size=(4, 4)) * 0.6
+    dp, dm = np.log([1., 2, 3, 4]), np.log([.5, 1.5, 2.5, 3.5])
+    rows = [list(rng.binomial(1, .6, 6)) + [1, o, 3] for o in (0, 1, 2)]
+    rows += [[1, 0, 0, 0, 1, 0, 0, -99, 0], [1, 0, 1, 0, 0, 0, 1, -99, 1], [0, 1, 0, 0, 0, 1, 1, -99, 2],
+             [0] * 6 + [1, 0, 3]]
+    dat = np.array(rows, dtype=np.int8)
+    s, gth, gdp, gdm = O.score_and_grad(lt, dp, dm, dat, 0.4)
+    h = 1e-6
+    for (i, j) in [(0, 0), (1, 2), (3, 1), (2, 3), (3, 3)]:
+        e = np.zeros((4, 4)); e[i, j] = h
+        fd = (O.score(lt + e, dp, dm, dat, 0.4) - O.score(lt - e, dp, dm, dat, 0.4)) / (2 * h)
+        assert abs(fd - gth[i, j]) < 1e-7
+    for i in range(4):
+        e = np.zeros(4); e[i] = h
+        assert abs((O.score(lt, dp + e, dm, dat, .4) - O.score(lt, dp - e, dm, dat, .4)) / (2 * h) - gdp[i]) < 1e-7
+        assert abs((O.score(lt, dp, dm + e, dat, .4) - O.score(lt, dp, dm - e, dat, .4)) / (2 * h) - gdm[i]) < 1e-7
