@@ -1,0 +1,126 @@
+/*
+ * metmhn_amd C ABI - MI355X (gfx950) likelihood / gradient engine for metMHN.
+ *
+ * The reference (cbg-ethz/metMHN @ 2024_08_07) has no FFI layer: its boundary is the
+ * Python call surface of metmhn/regularized_optimization.py and metmhn/jx/{kronvec,likelihood,vanilla}.py.  Every
+ * entry point below replaces one of those Python functions; the ctypes binding lives in
+ * metmhn_amd/_lib.py and the reference-side stub a maintainer would add is shown in
+ * INTEGRATION.md.  All pointers are caller-owned HOST buffers, row-major, fp64 at the
+ * interface whatever the engine's internal dtype; every function returns 0 on success
+ * and a non-zero status otherwise (message: mmhn_last_error(), thread-local).  A handle
+ * is bound to one GPU and is not thread-safe (the reference is single-threaded:
+ * scipy.optimize.minimize calls score_and_grad_reg synchronously,
+ * regularized_optimization.py:328-330).
+ *
+ * Layout conventions (regularized_optimization.py:63-66, metmhn/jx/kronvec.py:223-250):
+ *   dat    int8 [n_pat][2n+3]  = PT_0,MT_0,...,PT_{n-1},MT_{n-1},seed, order, type
+ *   state  int8 [2n+1]  joint observation;  [n+1] for the single-tumour functions
+ *   vectors have 2^k entries, k = #ones in state; index bit b <-> b-th active slot.
+ *   log_theta fp64 [n+1][n+1], log_d_p / log_d_m fp64 [n+1].
+ */
+#ifndef METMHN_AMD_H
+#define METMHN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmhn_engine* mmhn_handle;
+
+enum { MMHN_F64 = 0, MMHN_F32 = 1 };
+
+/* ---- lifetime ------------------------------------------------------------------- */
+int mmhn_create(int device_id, int n_mut, int dtype, mmhn_handle* out);
+void mmhn_destroy(mmhn_handle h);
+const char* mmhn_last_error(void);
+/* upper bound on device workspace used per batch of patients (default: 70 % of free HBM) */
+int mmhn_set_workspace_limit(mmhn_handle h, size_t bytes);
+
+/* ---- cohort objective -------------------------------------------------------------
+ * mmhn_set_cohort copies `dat`, derives every patient's bit layout and batches once.
+ * mmhn_score            <-> regularized_optimization.score           (:55-130)
+ * mmhn_score_and_grad   <-> regularized_optimization.score_and_grad  (:163-267)
+ * mmhn_cohort_sums returns the UNWEIGHTED partial sums of this handle's patients so that
+ * patient shards on several GPUs can be combined with one all-reduce:
+ *   sums[0]            = sum of log-probs of the rows with type != 0 ("EM")
+ *   sums[1]            = sum of log-probs of the rows with type == 0 ("NM")
+ *   sums[2]            = number of rows with seeding == 1,  sums[3] = number of rows
+ *   then d_theta_EM [N*N], d_theta_NM [N*N], d_dp_EM [N], d_dp_NM [N], d_dm_EM [N]
+ * (N = n_mut + 1; 4 + 2*N*N + 3*N doubles; gradient blocks are zero if with_grad == 0).
+ */
+int mmhn_set_cohort(mmhn_handle h, const int8_t* dat, int64_t n_pat, int n_cols);
+int mmhn_score(mmhn_handle h, const double* log_theta, const double* log_d_p, const double* log_d_m,
+               double perc_met, double* score);
+int mmhn_score_and_grad(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                        const double* log_d_m, double perc_met, double* score, double* d_theta,
+                        double* d_dp, double* d_dm);
+int mmhn_cohort_sums(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                     const double* log_d_m, int with_grad, double* sums);
+/* per-patient results of the current cohort (tests): lp[n_pat], and if non-NULL
+ * d_theta[n_pat][N*N], d_dp[n_pat][N], d_dm[n_pat][N]  (ssr._g_coupled_*, _grad_*_obs) */
+int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                       const double* log_d_m, double* lp, double* d_theta, double* d_dp, double* d_dm);
+
+/* ---- joint PT/MT primitives (metmhn/jx/kronvec.py, likelihood.py) ------------------
+ * mmhn_kronvec        <-> kronvec.kronvec        (:499-539)   y = Q p, flags diag / transpose
+ * mmhn_kron_diag      <-> kronvec.kron_diag      (:964-999)
+ * mmhn_diag_scal      <-> kronvec.diag_scal_p/m  (:574-602, :646-671)  which: 0 = p, 1 = m
+ * mmhn_obs_states     <-> kronvec.obs_states + jnp.where(size=) (:1056-1095, likelihood.py:280)
+ *                         ascending compatible indices; *count receives how many
+ * mmhn_resolvent      <-> likelihood.R_i_inv_vec (:231-262)   (D_p + D_m - Q)^-1 x
+ * mmhn_x_partial_Q_y  <-> likelihood.x_partial_Q_y (:163-201) G[N][N]
+ * mmhn_x_partial_D_y  <-> likelihood.x_partial_D_y (:204-228) (takes log_d_p, log_d_m in THAT order)
+ */
+int mmhn_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
+                 double* y, int diag, int transpose);
+int mmhn_kron_diag(mmhn_handle h, const double* log_theta, const int8_t* state, double* out);
+int mmhn_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, const double* p,
+                   double* y, int which);
+int mmhn_obs_states(mmhn_handle h, const int8_t* state, int pt_first, int64_t* idx, int64_t* count);
+int mmhn_resolvent(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                   const double* log_d_m, const int8_t* state, const double* x, double* y,
+                   int transpose);
+int mmhn_x_partial_Q_y(mmhn_handle h, const double* log_theta, const int8_t* state, const double* x,
+                       const double* y, double* G);
+int mmhn_x_partial_D_y(mmhn_handle h, const double* log_d_p, const double* log_d_m,
+                       const int8_t* state, const double* x, const double* y, double* d_dp,
+                       double* d_dm);
+
+/* ---- single-tumour primitives (metmhn/jx/vanilla.py); state has n+1 entries ---------
+ * mmhn_v_kronvec       <-> vanilla.kronvec        (:78-106)
+ * mmhn_v_resolvent     <-> vanilla.R_inv_vec      (:269-305)  d_rates == NULL means 1
+ * mmhn_v_x_partial_Q_y <-> vanilla.x_partial_Q_y  (:328-393)  G[N][N], d_diag[N]
+ */
+int mmhn_v_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
+                   double* y, int diag, int transpose);
+int mmhn_v_resolvent(mmhn_handle h, const double* log_theta, const int8_t* state,
+                     const double* d_rates, const double* x, double* y, int transpose);
+int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* log_theta, const int8_t* state,
+                         const double* x, const double* y, double* G, double* d_diag);
+
+/* ---- measurement -------------------------------------------------------------------
+ * mmhn_bench_kronvec: `batch` resident copies of a 2^k vector, `iters` back-to-back
+ * launches of the batched Q_off p kernel (or the fused Jacobi step if jacobi != 0) timed
+ * with HIP events on the engine's stream; returns the average launch duration in ms.
+ * mmhn_get_counters: cumulative figures since mmhn_reset_counters (events recorded on the
+ * engine's stream around every launch of the solve-sweep kernel).
+ */
+typedef struct {
+  double sweep_ms;        /* total duration of solve-sweep kernel launches */
+  int64_t sweep_launches; /* number of those launches */
+  double sweep_alg_bytes; /* algorithmic bytes they moved (4 * 2^k * sizeof(dtype) per state vector and sweep) */
+  double eval_ms;         /* host wall time spent inside mmhn_cohort_sums */
+  int64_t evals;
+} mmhn_counters;
+int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch,
+                       int iters, int transpose, int jacobi, double* ms_per_launch);
+int mmhn_get_counters(mmhn_handle h, mmhn_counters* out);
+int mmhn_reset_counters(mmhn_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METMHN_AMD_H */

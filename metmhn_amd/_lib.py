@@ -1,0 +1,104 @@
+"""Build and load the native library (libmetmhn_amd.so) through ctypes.
+
+The C ABI is declared in include/metmhn_amd.h.  There is no CPU fallback: if the
+library cannot be built/loaded, or no GPU is visible when an engine is created,
+the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("engine.hip", "kernels.h", "desc.h")]
+_HDR = os.path.join(_ROOT, "include", "metmhn_amd.h")
+LIB_PATH = os.path.join(_HERE, "libmetmhn_amd.so")
+
+f64p = C.POINTER(C.c_double)
+i8p = C.POINTER(C.c_int8)
+i64p = C.POINTER(C.c_int64)
+
+
+class Counters(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("sweep_launches", C.c_int64), ("sweep_alg_bytes", C.c_double),
+                ("eval_ms", C.c_double), ("evals", C.c_int64)]
+
+
+# name -> argtypes (every function returns int status unless noted)
+SIGNATURES = {
+    "mmhn_create": [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
+    "mmhn_set_workspace_limit": [C.c_void_p, C.c_size_t],
+    "mmhn_set_cohort": [C.c_void_p, i8p, C.c_int64, C.c_int],
+    "mmhn_score": [C.c_void_p, f64p, f64p, f64p, C.c_double, f64p],
+    "mmhn_score_and_grad": [C.c_void_p, f64p, f64p, f64p, C.c_double, f64p, f64p, f64p, f64p],
+    "mmhn_cohort_sums": [C.c_void_p, f64p, f64p, f64p, C.c_int, f64p],
+    "mmhn_patient_grads": [C.c_void_p, f64p, f64p, f64p, f64p, f64p, f64p, f64p],
+    "mmhn_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
+    "mmhn_kron_diag": [C.c_void_p, f64p, i8p, f64p],
+    "mmhn_diag_scal": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int],
+    "mmhn_obs_states": [C.c_void_p, i8p, C.c_int, i64p, i64p],
+    "mmhn_resolvent": [C.c_void_p, f64p, f64p, f64p, i8p, f64p, f64p, C.c_int],
+    "mmhn_x_partial_Q_y": [C.c_void_p, f64p, i8p, f64p, f64p, f64p],
+    "mmhn_x_partial_D_y": [C.c_void_p, f64p, f64p, i8p, f64p, f64p, f64p, f64p],
+    "mmhn_v_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
+    "mmhn_v_resolvent": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, C.c_int],
+    "mmhn_v_x_partial_Q_y": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, f64p],
+    "mmhn_bench_kronvec": [C.c_void_p, f64p, i8p, C.c_int64, C.c_int, C.c_int, C.c_int, f64p],
+    "mmhn_get_counters": [C.c_void_p, C.POINTER(Counters)],
+    "mmhn_reset_counters": [C.c_void_p],
+}
+OTHER_SYMBOLS = ("mmhn_destroy", "mmhn_last_error")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in _SRC + [_HDR])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into metmhn_amd/libmetmhn_amd.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-comment",
+           "-o", LIB_PATH, _SRC[0]]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library and attach the ctypes prototypes of include/metmhn_amd.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(metmhn_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.mmhn_destroy.argtypes = [C.c_void_p]
+    lib.mmhn_destroy.restype = None
+    lib.mmhn_last_error.argtypes = []
+    lib.mmhn_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != 0:
+        raise RuntimeError("metmhn_amd: " + load().mmhn_last_error().decode(errors="replace"))

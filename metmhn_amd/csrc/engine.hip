@@ -1,0 +1,900 @@
+// Host side of the metMHN engine: cohort layout, batch scheduling, kernel launches and the
+// C ABI of include/metmhn_amd.h.  One engine = one GPU, one HIP stream.
+//
+// Pipeline of one evaluation (reference call graph: regularized_optimization.py:163-267 ->
+// likelihood.py:_g_coupled_*, _grad_prim_obs, _grad_met_obs), run batch by batch with every
+// patient of the batch in flight at once:
+//   1  lidg_J = 1/(D_p + D_m - diag Q)                       k_diag(KD_LIDG)
+//   2  pi    = (D - Q)^-1 e_0          k+1 fused Jacobi sweeps  k_sweep<false>
+//   3  v     = D_obs * pi[compatible]  -> marginal right-hand sides  k_gather_marg
+//   4  single-tumour spaces (marginals of paired patients and the unpaired patients):
+//      lidg_S, forward solve, scores -> adjoint seeds 1/score, adjoint solve,
+//      flow gradient                  k_diag, k_sweep, k_seeds, k_sweep<true>, k_grad_rows
+//   5  rhs_J = D_obs * scatter(q_S), q_J = (D - Q)^-T rhs_J  k_scatter_marg, k_sweep<true>
+//   6  joint gradient: class marginals, eq block, flow rows, observation-rate marginals
+//                                      k_class_marg, k_eq_flows, k_grad_rows, k_bit_marg
+//   7  per-patient assembly and deterministic cohort reduction  k_finalize, k_reduce
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/metmhn_amd.h"
+#include "kernels.h"
+
+namespace mmhn {
+
+static thread_local std::string g_err;
+
+struct Fail {
+  std::string msg;
+};
+#define HIPCHECK(expr)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      throw Fail{std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                 std::to_string(__LINE__) + ")"};                                            \
+  } while (0)
+#define REQUIRE(cond, text) \
+  do {                      \
+    if (!(cond)) throw Fail{std::string(text)}; \
+  } while (0)
+
+template <typename U>
+struct DevArr {
+  U* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    release();
+    if (count == 0) return;
+    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(U)));
+    n = count;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevArr() { release(); }
+  DevArr() = default;
+  DevArr(const DevArr&) = delete;
+  DevArr& operator=(const DevArr&) = delete;
+  DevArr(DevArr&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevArr& operator=(DevArr&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+};
+
+// static (per cohort) description of one batch of patients
+struct Batch {
+  std::vector<PatRec> pats;
+  std::vector<Desc> dJ, dS;
+  std::vector<int2> mapJ, mapS;
+  long long vecJ = 0, vecS = 0, asize = 0;
+  int maxkJ = 0, maxkS = 0;
+  bool has_kind2 = false;
+  DevArr<PatRec> d_pats;
+  DevArr<Desc> d_dJ, d_dS;
+  DevArr<int2> d_mapJ, d_mapS;
+};
+
+static inline long long a_size(const Desc& d) {
+  const int kP = popc(d.maskP), kM = popc(d.maskM), kE = popc(d.pairP);
+  return ((long long)(kP + 1) << kP) + ((long long)(kM + 1) << kM) + ((long long)(kE + 2) << kE);
+}
+
+static void add_tiles(std::vector<int2>& map, int prob, int k) {
+  const int tiles = k > TB ? 1 << (k - TB) : 1;
+  for (int t = 0; t < tiles; ++t) map.push_back(make_int2(prob, t));
+}
+
+struct EngineBase {
+  virtual ~EngineBase() = default;
+  int dtype = 0;
+};
+
+template <typename T>
+struct Engine : EngineBase {
+  int device = 0, n = 0, N = 0;
+  hipStream_t stream = nullptr;
+  size_t ws_limit = 0;
+  DevArr<Params<T>> d_par;
+  std::vector<Params<T>> h_par;
+  // cohort
+  std::vector<int8_t> dat;
+  long long n_pat = 0;
+  int n_cols = 0;
+  std::vector<Batch> batches;
+  double n_em = 0;
+  // workspace (sized for the largest batch)
+  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, dots, bmJ, bmS;
+  DevArr<double> lp, out, sums;
+  // counters
+  mmhn_counters cnt{};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  std::vector<double> ev_bytes;
+
+  Engine(int dev, int n_mut) : device(dev), n(n_mut), N(n_mut + 1) {
+    REQUIRE(n_mut >= 1 && n_mut < MAXN, "n_mut must be in [1, 31]");
+    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    d_par.alloc(NPSET);
+    h_par.resize(NPSET);
+    sums.alloc(2 * stride());
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    ws_limit = (size_t)(0.7 * (double)free_b);
+    // kernels may need more than the default dynamic LDS window
+    const int lds = 150 * 1024;
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<T>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_rows<T>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  ~Engine() override {
+    (void)hipSetDevice(device);
+    for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int stride() const { return 1 + N * N + 2 * N; }
+
+  // ---------------------------------------------------------------- parameters
+  void build_params(const double* lt, const double* ldp, const double* ldm) {
+    std::vector<double> zero(N, 0.0);
+    if (!ldp) ldp = zero.data();
+    if (!ldm) ldm = zero.data();
+    for (int s = 0; s < NPSET; ++s) {
+      Params<T>& P = h_par[s];
+      std::memset(&P, 0, sizeof(P));
+      for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) {
+          double v = lt[i * N + j];
+          if (s == PS_PRIM && j == n && i < n) v = 0.0;             // likelihood.py:313
+          if (s == PS_MET && i != j) v -= ldm[j];                   // kronvec.py:18
+          if (s == PS_PRIM && i != j) v -= ldp[j];
+          P.th[i][j] = (T)std::exp(v);
+        }
+        P.baseP[i] = (T)std::exp(lt[i * N + i]);
+        P.baseM[i] = i < n ? (T)(std::exp(lt[i * N + i]) * std::exp(lt[i * N + n])) : (T)0;
+        P.dp[i] = (T)std::exp(ldp[i]);
+        P.dm[i] = (T)std::exp(ldm[i]);
+      }
+    }
+    HIPCHECK(hipMemcpyAsync(d_par.p, h_par.data(), NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
+  }
+
+  // ---------------------------------------------------------------- launches
+  size_t sweep_lds(int maxk) const { return DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)std::max(maxk, 1) * 64) * sizeof(T); }
+
+  void launch_sweep(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, const T* p, T* y,
+                    const T* lidg, const T* rhs, int rhs_mode, const T* scal, double alg_bytes) {
+    if (ntiles == 0) return;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = alg_bytes > 0;
+    if (timed) {
+      if (ev_used == ev_pool.size()) {
+        hipEvent_t a, b;
+        HIPCHECK(hipEventCreate(&a));
+        HIPCHECK(hipEventCreate(&b));
+        ev_pool.push_back({a, b});
+      }
+      e0 = ev_pool[ev_used].first;
+      e1 = ev_pool[ev_used].second;
+      ++ev_used;
+      ev_bytes.push_back(alg_bytes);
+      HIPCHECK(hipEventRecord(e0, stream));
+    }
+    const size_t lds = sweep_lds(maxk);
+    if (tr)
+      hipLaunchKernelGGL((k_sweep<T, true>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
+                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1));
+    else
+      hipLaunchKernelGGL((k_sweep<T, false>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
+                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1));
+    HIPCHECK(hipGetLastError());
+    if (timed) HIPCHECK(hipEventRecord(e1, stream));
+  }
+  void collect_events() {
+    for (size_t i = 0; i < ev_used; ++i) {
+      float ms = 0;
+      HIPCHECK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
+      cnt.sweep_ms += ms;
+      cnt.sweep_launches += 1;
+      cnt.sweep_alg_bytes += ev_bytes[i];
+    }
+    ev_used = 0;
+    ev_bytes.clear();
+  }
+
+  void launch_diag(const Desc* descs, const int2* map, int ntiles, const T* p, T* outp, const T* dvec, int what) {
+    if (ntiles == 0) return;
+    const size_t lds = DESC_PAD + ((size_t)4 * N * 64 + 256) * sizeof(T);
+    hipLaunchKernelGGL((k_diag<T>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, outp, dvec,
+                       what, N);
+    HIPCHECK(hipGetLastError());
+  }
+  void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind) {
+    if (nprob == 0) return;
+    const int maxhi = std::max(0, maxk - 6);
+    const size_t lds = ((size_t)WAVES * 64 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
+    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (N + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream, descs,
+                       d_par.p, A, p, q, G, kind, maxhi);
+    HIPCHECK(hipGetLastError());
+  }
+  void zero(T* p, long long count) {
+    if (count > 0) HIPCHECK(hipMemsetAsync(p, 0, (size_t)count * sizeof(T), stream));
+  }
+  // (D - Q)^-1 rhs on every problem of a list: k+1 in-place fused Jacobi sweeps from zero
+  void solve(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, long long vec, T* y, const T* lidg,
+             const T* rhs, int rhs_mode, const T* scal) {
+    if (ntiles == 0) return;
+    zero(y, vec);
+    const double bytes = 4.0 * (double)vec * sizeof(T);   // read y, lidg, rhs; write y (B_js)
+    for (int s = 0; s <= maxk; ++s) launch_sweep(tr, descs, map, ntiles, maxk, y, y, lidg, rhs, rhs_mode, scal, bytes);
+  }
+
+  // ---------------------------------------------------------------- cohort
+  void set_cohort(const int8_t* d_, long long np, int nc) {
+    REQUIRE(nc == 2 * n + 3, "dat must have 2*n_mut+3 columns");
+    REQUIRE(np >= 0, "negative patient count");
+    dat.assign(d_, d_ + np * nc);
+    n_pat = np;
+    n_cols = nc;
+    batches.clear();
+    n_em = 0;
+    size_t max_need = 0;
+    auto bytes_of = [&](const Batch& b) {
+      return (size_t)(4 * b.vecJ + 4 * b.vecS + b.asize) * sizeof(T) +
+             (size_t)(b.dS.size() * N * N + 3 * b.dJ.size() * N * N) * sizeof(T) +
+             b.pats.size() * (size_t)stride() * sizeof(double);
+    };
+    Batch cur;
+    auto flush = [&]() {
+      if (cur.pats.empty()) return;
+      max_need = std::max(max_need, bytes_of(cur));
+      batches.push_back(std::move(cur));
+      cur = Batch();
+    };
+    std::vector<int8_t> st(2 * n + 2);
+    for (long long r = 0; r < np; ++r) {
+      const int8_t* row = dat.data() + r * nc;
+      const int type = row[nc - 1];
+      const int order = row[nc - 2];
+      REQUIRE(type >= 0 && type <= 3, "dat: type column must be 0..3");
+      for (int c = 0; c < 2 * n + 1; ++c) REQUIRE(row[c] == 0 || row[c] == 1, "dat: event columns must be 0/1");
+      n_em += row[2 * n];
+      // problems of this patient
+      PatRec pr{};
+      pr.kind = type; pr.order = (order == 0 || order == 1) ? order : 2; pr.j = -1; pr.s[0] = pr.s[1] = -1;
+      pr.row = (int)r;
+      Desc dj{}, ds0{}, ds1{};
+      bool hasJ = false, has0 = false, has1 = false;
+      if (type == 0 || type == 1) {
+        for (int j = 0; j <= n; ++j) st[j] = row[2 * j];          // PT slots + seeding (regularized_optimization.py:189)
+        int np_ = 0;
+        for (int j = 0; j <= n; ++j) np_ += st[j];
+        if (type == 0 && np_ == 0) pr.kind = 4;
+        else { ds0 = make_single(st.data(), n, PS_PRIM, OBS_ONE); has0 = true; }
+      } else if (type == 2) {
+        for (int j = 0; j < n; ++j) st[j] = row[2 * j + 1];       // MT slots, seeding = 1 (:216-219)
+        st[n] = 1;
+        ds0 = make_single(st.data(), n, PS_THETA, OBS_MET);
+        has0 = true;
+      } else {
+        REQUIRE(row[2 * n] == 1, "dat: paired rows (type 3) must have seeding = 1");
+        dj = make_joint(row, n);
+        hasJ = true;
+        if (pr.order == 0 || pr.order == 1) {                     // PT observed first -> MT marginal
+          for (int j = 0; j < n; ++j) st[j] = row[2 * j + 1];
+          st[n] = 1;
+          ds0 = make_single(st.data(), n, PS_MET, OBS_ONE);
+          has0 = true;
+        }
+        if (pr.order != 1) {                                      // MT observed first -> PT marginal
+          for (int j = 0; j <= n; ++j) st[j] = row[2 * j];
+          ds1 = make_single(st.data(), n, PS_PRIM, OBS_ONE);
+          has1 = true;
+        }
+      }
+      REQUIRE(!hasJ || dj.k <= MAXK, "too many active events for one patient");
+      // would the batch overflow the workspace?
+      Batch probe;
+      probe.vecJ = cur.vecJ + (hasJ ? (1ll << dj.k) : 0);
+      probe.vecS = cur.vecS + (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
+      probe.asize = cur.asize + (hasJ ? a_size(dj) : 0);
+      const size_t need = (size_t)(4 * probe.vecJ + 4 * probe.vecS + probe.asize) * sizeof(T);
+      if (!cur.pats.empty() && need > ws_limit) flush();
+      if (hasJ) {
+        dj.off = cur.vecJ; dj.aoff = cur.asize;
+        cur.vecJ += 1ll << dj.k; cur.asize += a_size(dj);
+        pr.j = (int)cur.dJ.size();
+        add_tiles(cur.mapJ, pr.j, dj.k);
+        cur.maxkJ = std::max(cur.maxkJ, dj.k);
+        cur.dJ.push_back(dj);
+      }
+      if (has0) {
+        ds0.off = cur.vecS; cur.vecS += 1ll << ds0.k;
+        pr.s[0] = (int)cur.dS.size();
+        add_tiles(cur.mapS, pr.s[0], ds0.k);
+        cur.maxkS = std::max(cur.maxkS, ds0.k);
+        cur.dS.push_back(ds0);
+      }
+      if (has1) {
+        ds1.off = cur.vecS; cur.vecS += 1ll << ds1.k;
+        pr.s[1] = (int)cur.dS.size();
+        add_tiles(cur.mapS, pr.s[1], ds1.k);
+        cur.maxkS = std::max(cur.maxkS, ds1.k);
+        cur.dS.push_back(ds1);
+      }
+      if (pr.kind == 2) cur.has_kind2 = true;
+      cur.pats.push_back(pr);
+    }
+    flush();
+    // upload the static descriptions and size the workspace
+    long long mvJ = 0, mvS = 0, mA = 0;
+    size_t mnJ = 0, mnS = 0, mp = 0;
+    for (auto& b : batches) {
+      b.d_pats.alloc(b.pats.size());
+      HIPCHECK(hipMemcpy(b.d_pats.p, b.pats.data(), b.pats.size() * sizeof(PatRec), hipMemcpyHostToDevice));
+      auto up = [&](auto& dev, auto& host) {
+        if (host.empty()) return;
+        dev.alloc(host.size());
+        HIPCHECK(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
+      };
+      up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
+      mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
+      mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
+    }
+    pi.alloc(mvJ); lidgJ.alloc(mvJ); qJ.alloc(mvJ); rhsJ.alloc(mvJ);
+    rhsS.alloc(mvS); pS.alloc(mvS); lidgS.alloc(mvS); qS.alloc(mvS);
+    seedS.alloc(mnS); Abuf.alloc(mA);
+    GS.alloc(mnS * N * N); GJ.alloc(3 * mnJ * N * N);
+    dots.alloc(2 * mp); bmJ.alloc(mnJ * 64); bmS.alloc(mnS * 64);
+    lp.alloc(mp); out.alloc(mp * stride());
+  }
+
+  void fill_e0(const Batch& b) {
+    const int npat = (int)b.pats.size();
+    if (b.dS.empty()) return;
+    hipLaunchKernelGGL((k_fill_e0<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
+                       rhsS.p);
+    HIPCHECK(hipGetLastError());
+  }
+
+  // ---------------------------------------------------------------- one evaluation
+  // host_out (optional): per-patient rows [n_pat][stride]; sums: [2][stride] (EM, NM)
+  void evaluate(const double* lt, const double* ldp, const double* ldm, bool grad, double* host_sums,
+                double* host_out) {
+    auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(hipSetDevice(device));
+    build_params(lt, ldp, ldm);
+    const int st = stride();
+    HIPCHECK(hipMemsetAsync(sums.p, 0, 2 * st * sizeof(double), stream));
+    for (Batch& b : batches) {
+      const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
+      const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
+      // 1-2 joint forward
+      launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
+      solve(false, b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, pi.p, lidgJ.p, nullptr, 2, nullptr);
+      // 3 marginal right-hand sides
+      zero(rhsS.p, b.vecS);
+      if (nJ) {
+        hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, 8), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
+                           b.d_dS.p, d_par.p, pi.p, rhsS.p);
+        HIPCHECK(hipGetLastError());
+      }
+      fill_e0(b);
+      // 4 single-tumour spaces
+      launch_diag(b.d_dS.p, b.d_mapS.p, tS, nullptr, lidgS.p, nullptr, KD_LIDG);
+      solve(false, b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
+      hipLaunchKernelGGL((k_seeds<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
+                         d_par.p, pS.p, seedS.p, lp.p);
+      HIPCHECK(hipGetLastError());
+      if (grad) {
+        solve(true, b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, qS.p, lidgS.p, nullptr, 1, seedS.p);
+        launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S);
+        if (b.has_kind2) {
+          zero(bmS.p, (long long)nS * 64);
+          hipLaunchKernelGGL((k_bit_marg<T>), dim3(tS), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapS.p, d_par.p,
+                             pS.p, qS.p, bmS.p);
+          HIPCHECK(hipGetLastError());
+        }
+        if (nJ) {
+          // 5 joint adjoint
+          zero(rhsJ.p, b.vecJ);
+          for (int part = 0; part < 2; ++part) {
+            hipLaunchKernelGGL((k_scatter_marg<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
+                               b.d_dS.p, d_par.p, qS.p, rhsS.p, rhsJ.p, dots.p, part);
+            HIPCHECK(hipGetLastError());
+          }
+          solve(true, b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
+          // 6 joint gradient
+          hipLaunchKernelGGL((k_class_marg<T>), dim3(nJ, 2, 4), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p,
+                             Abuf.p);
+          HIPCHECK(hipGetLastError());
+          hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+          HIPCHECK(hipGetLastError());
+          const long long gjs = (long long)nJ * N * N;
+          for (int kd = 0; kd < 3; ++kd)
+            launch_grad_rows(b.d_dJ.p, nJ, b.maxkJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd);
+          zero(bmJ.p, (long long)nJ * 64);
+          hipLaunchKernelGGL((k_bit_marg<T>), dim3(tJ), dim3(BLOCK), 0, stream, b.d_dJ.p, b.d_mapJ.p, d_par.p, pi.p,
+                             qJ.p, bmJ.p);
+          HIPCHECK(hipGetLastError());
+        }
+        // 7 assembly
+      }
+      hipLaunchKernelGGL((k_finalize<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p, b.d_dS.p,
+                         d_par.p, GS.p, GJ.p, (long long)nJ * N * N, dots.p, bmJ.p, bmS.p, lp.p, out.p, N,
+                         grad ? 1 : 0);
+      HIPCHECK(hipGetLastError());
+      hipLaunchKernelGGL(k_reduce, dim3(grad ? st : 1, 2), dim3(BLOCK), 0, stream, b.d_pats.p, npat, out.p, st,
+                         sums.p);
+      HIPCHECK(hipGetLastError());
+      if (host_out) {
+        std::vector<double> tmp((size_t)npat * st);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), out.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        for (int i = 0; i < npat; ++i)
+          std::memcpy(host_out + (size_t)b.pats[i].row * st, tmp.data() + (size_t)i * st, st * sizeof(double));
+      }
+    }
+    std::vector<double> hs(2 * st);
+    HIPCHECK(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    collect_events();
+    if (host_sums) std::memcpy(host_sums, hs.data(), hs.size() * sizeof(double));
+    cnt.eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    cnt.evals += 1;
+  }
+
+  // sums layout of the C ABI (include/metmhn_amd.h)
+  void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
+    const int st = stride();
+    std::vector<double> hs(2 * st);
+    evaluate(lt, ldp, ldm, grad, hs.data(), nullptr);
+    const double* em = hs.data();
+    const double* nm = hs.data() + st;
+    o[0] = em[0]; o[1] = nm[0]; o[2] = n_em; o[3] = (double)n_pat;
+    double* q = o + 4;
+    std::memcpy(q, em + 1, N * N * sizeof(double)); q += N * N;
+    std::memcpy(q, nm + 1, N * N * sizeof(double)); q += N * N;
+    std::memcpy(q, em + 1 + N * N, N * sizeof(double)); q += N;
+    std::memcpy(q, nm + 1 + N * N, N * sizeof(double)); q += N;
+    std::memcpy(q, em + 1 + N * N + N, N * sizeof(double));
+  }
+
+  // ---------------------------------------------------------------- single-problem primitives (API / tests)
+  struct Mini {
+    Desc d;
+    DevArr<Desc> dd;
+    DevArr<int2> map;
+    int ntiles = 0;
+    DevArr<T> a, b, c, e;
+  };
+  void mini_setup(Mini& m, const Desc& d) {
+    m.d = d;
+    m.d.off = 0; m.d.aoff = 0;
+    REQUIRE(d.k <= MAXK, "too many active events");
+    std::vector<int2> mp;
+    add_tiles(mp, 0, d.k);
+    m.ntiles = (int)mp.size();
+    m.dd.alloc(1); m.map.alloc(mp.size());
+    HIPCHECK(hipMemcpyAsync(m.dd.p, &m.d, sizeof(Desc), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(m.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+  }
+  void up(DevArr<T>& dst, const double* src, size_t count) {
+    dst.alloc(count);
+    std::vector<T> tmp(src, src + count);
+    HIPCHECK(hipMemcpyAsync(dst.p, tmp.data(), count * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+  }
+  void down(double* dst, const T* src, size_t count) {
+    std::vector<T> tmp(count);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), src, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < count; ++i) dst[i] = (double)tmp[i];
+  }
+
+  void api_kronvec(const Desc& d, const double* p, double* y, bool diag, bool tr) {
+    Mini m; mini_setup(m, d);
+    const size_t V = (size_t)1 << d.k;
+    up(m.a, p, V);
+    m.b.alloc(V);
+    launch_sweep(tr, m.dd.p, m.map.p, m.ntiles, d.k, m.a.p, m.b.p, nullptr, nullptr, 0, nullptr, 0);
+    if (diag) launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, KD_ADDQP);
+    down(y, m.b.p, V);
+  }
+  void api_diag(const Desc& d, const double* p, double* outp, int what) {
+    Mini m; mini_setup(m, d);
+    const size_t V = (size_t)1 << d.k;
+    if (p) up(m.a, p, V);
+    m.b.alloc(V);
+    launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, what);
+    down(outp, m.b.p, V);
+  }
+  void api_resolvent(Desc d, const double* dvec, const double* x, double* y, bool tr) {
+    if (dvec) d.obs = OBS_VEC;
+    Mini m; mini_setup(m, d);
+    const size_t V = (size_t)1 << d.k;
+    up(m.a, x, V);
+    if (dvec) up(m.e, dvec, V);
+    m.b.alloc(V); m.c.alloc(V);
+    launch_diag(m.dd.p, m.map.p, m.ntiles, nullptr, m.c.p, m.e.p, KD_LIDG);
+    solve(tr, m.dd.p, m.map.p, m.ntiles, d.k, (long long)V, m.b.p, m.c.p, m.a.p, 0, nullptr);
+    down(y, m.b.p, V);
+  }
+  void api_xQy_joint(const Desc& d0, const double* x, const double* y, double* G) {
+    Mini m; mini_setup(m, d0);
+    const size_t V = (size_t)1 << d0.k;
+    up(m.a, y, V);   // p (right vector)
+    up(m.b, x, V);   // q (left vector)
+    m.c.alloc((size_t)a_size(m.d));
+    m.e.alloc((size_t)3 * N * N);
+    hipLaunchKernelGGL((k_class_marg<T>), dim3(1, 2, 4), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
+    HIPCHECK(hipGetLastError());
+    for (int kd = 0; kd < 3; ++kd) launch_grad_rows(m.dd.p, 1, d0.k, m.c.p, nullptr, nullptr, m.e.p + kd * N * N, kd);
+    std::vector<double> g(3 * N * N);
+    down(g.data(), m.e.p, g.size());
+    for (int e = 0; e < N * N; ++e) G[e] = g[e] + g[N * N + e] + g[2 * N * N + e];
+  }
+  void api_xQy_single(const Desc& d0, const double* x, const double* y, double* G, double* ddiag) {
+    Mini m; mini_setup(m, d0);
+    const size_t V = (size_t)1 << d0.k;
+    up(m.a, y, V);
+    up(m.b, x, V);
+    m.e.alloc((size_t)N * N);
+    launch_grad_rows(m.dd.p, 1, d0.k, nullptr, m.a.p, m.b.p, m.e.p, GK_S);
+    down(G, m.e.p, (size_t)N * N);
+    if (ddiag)
+      for (int j = 0; j < N; ++j) {
+        double s = 0;
+        for (int i = 0; i < N; ++i) if (i != j) s -= G[i * N + j];
+        ddiag[j] = s;
+      }
+  }
+  void api_xDy_joint(const Desc& d0, const double* x, const double* y, double* ddp, double* ddm) {
+    Mini m; mini_setup(m, d0);
+    const size_t V = (size_t)1 << d0.k;
+    up(m.a, y, V);
+    up(m.b, x, V);
+    m.e.alloc(64);
+    zero(m.e.p, 64);
+    hipLaunchKernelGGL((k_bit_marg<T>), dim3(m.ntiles), dim3(BLOCK), 0, stream, m.dd.p, m.map.p, d_par.p, m.a.p,
+                       m.b.p, m.e.p);
+    HIPCHECK(hipGetLastError());
+    double bm[64];
+    down(bm, m.e.p, 64);
+    for (int i = 0; i < N; ++i) {
+      const int bp = i == n ? d0.seedbit : d0.bitP[i];
+      const int bq = i == n ? d0.seedbit : d0.bitM[i];
+      ddp[i] = bp >= 0 ? bm[bp] : 0.0;
+      ddm[i] = bq >= 0 ? bm[32 + bq] : 0.0;
+    }
+  }
+  double bench_kronvec(const Desc& d0, long long batch, int iters, bool tr, bool jacobi) {
+    REQUIRE(batch >= 1 && iters >= 1, "batch and iters must be positive");
+    const long long V = 1ll << d0.k;
+    std::vector<Desc> ds((size_t)batch, d0);
+    std::vector<int2> mp;
+    for (long long i = 0; i < batch; ++i) { ds[i].off = i * V; ds[i].aoff = 0; add_tiles(mp, (int)i, d0.k); }
+    DevArr<Desc> dd; DevArr<int2> dm; DevArr<T> a, b, c, r;
+    dd.alloc(ds.size()); dm.alloc(mp.size());
+    HIPCHECK(hipMemcpy(dd.p, ds.data(), ds.size() * sizeof(Desc), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dm.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice));
+    a.alloc((size_t)(batch * V)); b.alloc((size_t)(batch * V));
+    std::vector<T> host((size_t)V);
+    for (long long i = 0; i < V; ++i) host[(size_t)i] = (T)(1.0 / (double)(1 + (i % 97)));
+    for (long long i = 0; i < batch; ++i)
+      HIPCHECK(hipMemcpy(a.p + i * V, host.data(), (size_t)V * sizeof(T), hipMemcpyHostToDevice));
+    if (jacobi) {
+      c.alloc((size_t)(batch * V)); r.alloc((size_t)(batch * V));
+      launch_diag(dd.p, dm.p, (int)mp.size(), nullptr, c.p, nullptr, KD_LIDG);
+      HIPCHECK(hipMemcpyAsync(r.p, a.p, (size_t)(batch * V) * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    }
+    auto run = [&]() {
+      launch_sweep(tr, dd.p, dm.p, (int)mp.size(), d0.k, a.p, b.p, jacobi ? c.p : nullptr, jacobi ? r.p : nullptr, 0,
+                   nullptr, 0);
+    };
+    run(); run();
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) run();
+    HIPCHECK(hipEventRecord(e1, stream));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)ms / iters;
+  }
+};
+
+// compatible indices (obs_states + jnp.where(size=)): integer host arithmetic, bit-exact
+static void obs_indices(const Desc& d, bool pt_first, int64_t* idx, int64_t* count) {
+  REQUIRE(d.seedbit >= 0, "obs_states needs an active seeding slot");
+  const uint32_t fixed = (pt_first ? d.maskP : d.maskM) | (1u << d.seedbit);
+  const uint32_t free_ = pt_first ? d.maskM : d.maskP;
+  const int64_t cntv = (int64_t)1 << popc(free_);
+  for (int64_t e = 0; e < cntv; ++e) {
+    uint32_t v = (uint32_t)e, m = free_, o = 0;
+    while (m) { const uint32_t low = m & (0u - m); if (v & 1u) o |= low; v >>= 1; m ^= low; }
+    idx[e] = (int64_t)(o | fixed);
+  }
+  *count = cntv;
+}
+
+}  // namespace mmhn
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+using namespace mmhn;
+
+struct mmhn_engine {
+  int dtype;
+  int n;
+  EngineBase* impl;
+};
+
+#define API_BEGIN try {
+#define API_END                                   \
+  return 0;                                       \
+  }                                               \
+  catch (const Fail& f) { g_err = f.msg; return 1; } \
+  catch (const std::exception& e) { g_err = e.what(); return 2; }
+
+#define DISPATCH(h, call)                                             \
+  do {                                                                \
+    REQUIRE(h && h->impl, "null handle");                             \
+    if (h->dtype == MMHN_F64) static_cast<Engine<double>*>(h->impl)->call; \
+    else static_cast<Engine<float>*>(h->impl)->call;                  \
+  } while (0)
+
+extern "C" {
+
+const char* mmhn_last_error(void) { return g_err.c_str(); }
+
+int mmhn_create(int device_id, int n_mut, int dtype, mmhn_handle* out) {
+  API_BEGIN
+  REQUIRE(out, "null out pointer");
+  REQUIRE(dtype == MMHN_F64 || dtype == MMHN_F32, "dtype must be MMHN_F64 or MMHN_F32");
+  int ndev = 0;
+  HIPCHECK(hipGetDeviceCount(&ndev));
+  REQUIRE(ndev > 0, "no HIP device visible: metmhn_amd needs a GPU (no CPU fallback)");
+  REQUIRE(device_id >= 0 && device_id < ndev, "device_id out of range");
+  auto* h = new mmhn_engine{dtype, n_mut, nullptr};
+  try {
+    if (dtype == MMHN_F64) h->impl = new Engine<double>(device_id, n_mut);
+    else h->impl = new Engine<float>(device_id, n_mut);
+  } catch (...) { delete h; throw; }
+  h->impl->dtype = dtype;
+  *out = h;
+  API_END
+}
+
+void mmhn_destroy(mmhn_handle h) {
+  if (!h) return;
+  delete h->impl;
+  delete h;
+}
+
+int mmhn_set_workspace_limit(mmhn_handle h, size_t bytes) {
+  API_BEGIN
+  REQUIRE(bytes >= (size_t)1 << 20, "workspace limit below 1 MiB");
+  DISPATCH(h, ws_limit = bytes);
+  API_END
+}
+
+int mmhn_set_cohort(mmhn_handle h, const int8_t* dat, int64_t n_pat, int n_cols) {
+  API_BEGIN
+  REQUIRE(dat || n_pat == 0, "null dat");
+  DISPATCH(h, set_cohort(dat, n_pat, n_cols));
+  API_END
+}
+
+static void weights(double n_em, double n_pat, double perc_met, double* w, double* n_full) {
+  const double n_nm = n_pat - n_em;                       // regularized_optimization.py:121-128
+  *w = (n_em * n_nm != 0) ? perc_met * n_nm / ((1 - perc_met) * n_em) : 1.0;
+  *n_full = *w * n_em + n_nm;
+}
+
+int mmhn_cohort_sums(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, int with_grad,
+                     double* sums) {
+  API_BEGIN
+  REQUIRE(lt && ldp && ldm && sums, "null pointer");
+  DISPATCH(h, cohort_sums(lt, ldp, ldm, with_grad != 0, sums));
+  API_END
+}
+
+int mmhn_score_and_grad(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, double perc_met,
+                        double* score, double* d_theta, double* d_dp, double* d_dm) {
+  API_BEGIN
+  REQUIRE(lt && ldp && ldm && score, "null pointer");
+  const int N = h->n + 1;
+  const bool grad = d_theta && d_dp && d_dm;
+  std::vector<double> s(4 + 2 * N * N + 3 * N);
+  DISPATCH(h, cohort_sums(lt, ldp, ldm, grad, s.data()));
+  double w, nf;
+  weights(s[2], s[3], perc_met, &w, &nf);
+  *score = (w * s[0] + s[1]) / nf;
+  if (grad) {
+    const double* gem = s.data() + 4;
+    const double* gnm = gem + N * N;
+    const double* pem = gnm + N * N;
+    const double* pnm = pem + N;
+    const double* mem_ = pnm + N;
+    for (int e = 0; e < N * N; ++e) d_theta[e] = (w * gem[e] + gnm[e]) / nf;
+    for (int i = 0; i < N; ++i) { d_dp[i] = (w * pem[i] + pnm[i]) / nf; d_dm[i] = w * mem_[i] / nf; }
+  }
+  API_END
+}
+
+int mmhn_score(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, double perc_met,
+               double* score) {
+  return mmhn_score_and_grad(h, lt, ldp, ldm, perc_met, score, nullptr, nullptr, nullptr);
+}
+
+int mmhn_patient_grads(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, double* lp,
+                       double* d_theta, double* d_dp, double* d_dm) {
+  API_BEGIN
+  REQUIRE(lt && ldp && ldm && lp, "null pointer");
+  const int N = h->n + 1, st = 1 + N * N + 2 * N;
+  long long np = 0;
+  if (h->dtype == MMHN_F64) np = static_cast<Engine<double>*>(h->impl)->n_pat;
+  else np = static_cast<Engine<float>*>(h->impl)->n_pat;
+  std::vector<double> rows((size_t)np * st), s(2 * st);
+  const bool grad = d_theta != nullptr;
+  DISPATCH(h, evaluate(lt, ldp, ldm, grad, s.data(), rows.data()));
+  for (long long i = 0; i < np; ++i) {
+    const double* r = rows.data() + (size_t)i * st;
+    lp[i] = r[0];
+    if (grad) {
+      std::memcpy(d_theta + (size_t)i * N * N, r + 1, N * N * sizeof(double));
+      if (d_dp) std::memcpy(d_dp + (size_t)i * N, r + 1 + N * N, N * sizeof(double));
+      if (d_dm) std::memcpy(d_dm + (size_t)i * N, r + 1 + N * N + N, N * sizeof(double));
+    }
+  }
+  API_END
+}
+
+// ---- joint primitives
+#define JOINT_DESC(state) make_joint(state, h->n)
+
+int mmhn_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const double* p, double* y, int diag,
+                 int transpose) {
+  API_BEGIN
+  REQUIRE(lt && state && p && y, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_kronvec(d, p, y, diag != 0, transpose != 0));
+  API_END
+}
+int mmhn_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, double* out) {
+  API_BEGIN
+  REQUIRE(lt && state && out, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_diag(d, nullptr, out, KD_DQ));
+  API_END
+}
+int mmhn_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, const double* p, double* y, int which) {
+  API_BEGIN
+  REQUIRE(log_d && state && p && y, "null pointer");
+  REQUIRE(which == 0 || which == 1, "which must be 0 (d_p) or 1 (d_m)");
+  const Desc d = JOINT_DESC(state);
+  REQUIRE(d.seedbit >= 0, "diag_scal needs an active seeding slot");
+  const int N = h->n + 1;
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), which == 0 ? log_d : nullptr, which == 1 ? log_d : nullptr));
+  DISPATCH(h, api_diag(d, p, y, which == 0 ? KD_DP : KD_DM));
+  API_END
+}
+int mmhn_obs_states(mmhn_handle h, const int8_t* state, int pt_first, int64_t* idx, int64_t* count) {
+  API_BEGIN
+  REQUIRE(h && state && idx && count, "null pointer");
+  obs_indices(JOINT_DESC(state), pt_first != 0, idx, count);
+  API_END
+}
+int mmhn_resolvent(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, const int8_t* state,
+                   const double* x, double* y, int transpose) {
+  API_BEGIN
+  REQUIRE(lt && ldp && ldm && state && x && y, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, ldp, ldm));
+  DISPATCH(h, api_resolvent(d, nullptr, x, y, transpose != 0));
+  API_END
+}
+int mmhn_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, const double* x, const double* y,
+                       double* G) {
+  API_BEGIN
+  REQUIRE(lt && state && x && y && G, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_xQy_joint(d, x, y, G));
+  API_END
+}
+int mmhn_x_partial_D_y(mmhn_handle h, const double* ldp, const double* ldm, const int8_t* state, const double* x,
+                       const double* y, double* d_dp, double* d_dm) {
+  API_BEGIN
+  REQUIRE(ldp && ldm && state && x && y && d_dp && d_dm, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  const int N = h->n + 1;
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), ldp, ldm));
+  DISPATCH(h, api_xDy_joint(d, x, y, d_dp, d_dm));
+  API_END
+}
+
+// ---- single-tumour primitives
+int mmhn_v_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const double* p, double* y, int diag,
+                   int transpose) {
+  API_BEGIN
+  REQUIRE(lt && state && p && y, "null pointer");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_kronvec(d, p, y, diag != 0, transpose != 0));
+  API_END
+}
+int mmhn_v_resolvent(mmhn_handle h, const double* lt, const int8_t* state, const double* d_rates, const double* x,
+                     double* y, int transpose) {
+  API_BEGIN
+  REQUIRE(lt && state && x && y, "null pointer");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_resolvent(d, d_rates, x, y, transpose != 0));
+  API_END
+}
+int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, const double* x, const double* y,
+                         double* G, double* d_diag) {
+  API_BEGIN
+  REQUIRE(lt && state && x && y && G, "null pointer");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_xQy_single(d, x, y, G, d_diag));
+  API_END
+}
+
+// ---- measurement
+int mmhn_bench_kronvec(mmhn_handle h, const double* lt, const int8_t* state, int64_t batch, int iters,
+                       int transpose, int jacobi, double* ms_per_launch) {
+  API_BEGIN
+  REQUIRE(lt && state && ms_per_launch, "null pointer");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  if (h->dtype == MMHN_F64)
+    *ms_per_launch = static_cast<Engine<double>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0);
+  else
+    *ms_per_launch = static_cast<Engine<float>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0);
+  API_END
+}
+int mmhn_get_counters(mmhn_handle h, mmhn_counters* out) {
+  API_BEGIN
+  REQUIRE(h && h->impl && out, "null pointer");
+  if (h->dtype == MMHN_F64) *out = static_cast<Engine<double>*>(h->impl)->cnt;
+  else *out = static_cast<Engine<float>*>(h->impl)->cnt;
+  API_END
+}
+int mmhn_reset_counters(mmhn_handle h) {
+  API_BEGIN
+  DISPATCH(h, cnt = mmhn_counters{});
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,766 @@
+// gfx950 kernels of the metMHN hot path (closed-form "gather" formulation).
+//
+// Work decomposition shared by the streaming kernels: a problem's 2^k state vector is cut
+// into tiles of 2^t contiguous states (t = min(k, TB)); one 256-thread workgroup owns one
+// tile, `map[blockIdx.x] = {problem, tile}`.  Inside a tile lane l of a wave owns the states
+// whose low 6 index bits are l, waves walk the 64-state rows.  Every transition rate is
+//     rate_b(x) = Ltab[b][lane] * Utab[b][row]
+// (a per-lane constant times a wave-uniform factor): the product over the bits of x that act
+// on event ev(b) splits into lane bits (0..5), row bits (6..t-1) and tile bits (t..k-1); both
+// tables live in LDS and are rebuilt per tile from the active theta row.  Neighbour states
+// x ^ bit are read from the LDS copy of the tile when the bit is below t and as coalesced
+// global loads otherwise.  HBM-bound elementwise / permute work: no MFMA.
+//
+// Reference semantics: metmhn/jx/kronvec.py (kronvec :499-539, kron_diag :964-999,
+// diag_scal_* :574-671, obs_states :1056-1095), likelihood.py (R_i_inv_vec :231-262,
+// x_partial_Q_y :163-201, x_partial_D_y :204-228), vanilla.py (single-tumour versions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "desc.h"
+
+namespace mmhn {
+
+constexpr int TB = 12;        // tile bits
+constexpr int BLOCK = 256;    // threads per workgroup
+constexpr int WAVES = BLOCK / 64;
+constexpr int DESC_WORDS = (sizeof(Desc) + 3) / 4;
+constexpr int DESC_PAD = ((sizeof(Desc) + 15) / 16) * 16;
+
+__device__ __forceinline__ void load_desc(Desc* dst, const Desc* src) {
+  const int* s = reinterpret_cast<const int*>(src);
+  int* d = reinterpret_cast<int*>(dst);
+  for (int i = threadIdx.x; i < DESC_WORDS; i += blockDim.x) d[i] = s[i];
+}
+
+// eq(x) without the seeding bit: PT(x) == MT(x) on paired events, lone bits clear
+__device__ __forceinline__ bool eq_noseed(const Desc& d, uint32_t x) {
+  return ((x & d.lone) == 0) && (((x & d.pairP) << 1) == (x & (d.pairP << 1)));
+}
+__device__ __forceinline__ bool seed_set(const Desc& d, uint32_t x) {
+  return d.mode == SINGLE || (d.seedbit >= 0 && ((x >> d.seedbit) & 1u));
+}
+
+// ------------------------------------------------------------------------------------
+// k_sweep: y = Q_off p  (TR: Q_off^T p), optionally fused Jacobi step
+//          y = lidg * (Q_off p + rhs)      (likelihood.py:253-255, vanilla.py:289-290)
+// rhs_mode: 0 dense vector, 1 scal[prob] * e_last, 2 e_0.  p and y may alias (in-place
+// Jacobi is exact after k+1 sweeps because Q_off is nilpotent and triangular).
+// ------------------------------------------------------------------------------------
+template <typename T, bool TR>
+__global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
+                                                 const int2* __restrict__ map,
+                                                 const Params<T>* __restrict__ par, const T* p, T* y,
+                                                 const T* __restrict__ lidg,
+                                                 const T* __restrict__ rhs, int rhs_mode,
+                                                 const T* __restrict__ scal, int maxk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Desc& d = *reinterpret_cast<Desc*>(smem);
+  T* tile = reinterpret_cast<T*>(smem + DESC_PAD);
+  T* Ltab = tile + (1 << TB);
+  T* Utab = Ltab + maxk * 64;
+  const int tid = threadIdx.x;
+  const int prob = map[blockIdx.x].x;
+  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  load_desc(&d, descs + prob);
+  __syncthreads();
+  const int k = d.k;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t, tmask = nelem - 1;
+  const long long base = d.off;
+  const int R = t > 6 ? 1 << (t - 6) : 1;
+  const Params<T>& P = par[d.pset];
+
+  for (uint32_t e = tid; e < nelem; e += BLOCK) tile[e] = p[base + ((long long)H << t) + e];
+  const int nl = k < 6 ? k : 6;
+  for (int e = tid; e < k * 64; e += BLOCK) {
+    const int b = e >> 6, l = e & 63;
+    const int row = d.ev[b];
+    const int c = d.cls[b];
+    const int pc = c == CS ? CP : c;
+    T v = 1;
+    for (int bb = 0; bb < nl; ++bb)
+      if (bb != b && ((l >> bb) & 1) && d.cls[bb] == pc) v *= P.th[row][d.ev[bb]];
+    Ltab[e] = v;
+    if (l < R) {
+      T u = (c == CM) ? P.baseM[row] : P.baseP[row];
+      for (int bb = 6; bb < t; ++bb)
+        if (bb != b && ((l >> (bb - 6)) & 1) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
+      for (int bb = t; bb < k; ++bb)
+        if (bb != b && ((H >> (bb - t)) & 1u) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
+      Utab[e] = u;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool joint = d.mode == JOINT;
+  const uint32_t last = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
+  for (int r = wave; r < R; r += WAVES) {
+    const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+    if (xl >= nelem) continue;
+    const uint32_t x = (H << t) | xl;
+    const bool ss = seed_set(d, x);
+    const bool e0x = eq_noseed(d, x);
+    T acc = 0;
+    for (int b = 0; b < k; ++b) {
+      const uint32_t bit = 1u << b;
+      const bool has = (x >> b) & 1u;
+      const int c = d.cls[b];
+      uint32_t nb = x ^ bit;
+      bool cond;
+      if (joint && c == CS) {
+        cond = (TR ? !has : has) && e0x;                     // seeding event (kronvec.py:434-496)
+      } else if (ss) {
+        cond = TR ? !has : has;                              // PT / MT event after seeding (:290-431)
+      } else if ((d.pairP >> b) & 1u) {
+        const uint32_t both = 3u << b;                       // synchronised event before seeding (:214-287)
+        nb = x ^ both;
+        cond = e0x && (TR ? (x & both) == 0 : (x & both) == both);
+      } else {
+        cond = false;
+      }
+      if (cond) {
+        const T v = ((nb >> t) == H) ? tile[nb & tmask] : p[base + nb];
+        acc += Ltab[b * 64 + lane] * Utab[b * 64 + r] * v;
+      }
+    }
+    T out = acc;
+    if (lidg) {
+      T rv;
+      if (rhs_mode == 0) rv = rhs[base + x];
+      else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
+      else rv = (x == 0) ? T(1) : T(0);
+      out = lidg[base + x] * (acc + rv);
+    }
+    y[base + x] = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// k_diag: diagonal quantities of one tile.
+//   KD_DQ    out = diag(Q)                           (kron_diag, kronvec.py:964-999)
+//   KD_LIDG  out = 1 / (Dobs - diag(Q))              (likelihood.py:249-250, vanilla.py:294)
+//   KD_ADDQP out += diag(Q) * p                      (completes kronvec(diag=True))
+//   KD_DP    out = D_p * p,  KD_DM  out = D_m * p    (diag_scal_p / diag_scal_m)
+// ------------------------------------------------------------------------------------
+enum { KD_DQ = 0, KD_LIDG = 1, KD_ADDQP = 2, KD_DP = 3, KD_DM = 4 };
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
+                                                const int2* __restrict__ map,
+                                                const Params<T>* __restrict__ par,
+                                                const T* __restrict__ p, T* out,
+                                                const T* __restrict__ dvec, int what, int maxN) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Desc& d = *reinterpret_cast<Desc*>(smem);
+  T* LcP = reinterpret_cast<T*>(smem + DESC_PAD);
+  T* UcP = LcP + maxN * 64;
+  T* LcM = UcP + maxN * 64;
+  T* UcM = LcM + maxN * 64;
+  T* LA = UcM + maxN * 64;     // obs products: A = dp over P bits (SINGLE: non-seeding bits)
+  T* UA = LA + 64;
+  T* LB = UA + 64;             //               B = dm over M bits (SINGLE: non-seeding bits)
+  T* UB = LB + 64;
+  const int tid = threadIdx.x;
+  const int prob = map[blockIdx.x].x;
+  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  load_desc(&d, descs + prob);
+  __syncthreads();
+  const int k = d.k, N = d.N, n = N - 1;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t;
+  const long long base = d.off;
+  const int R = t > 6 ? 1 << (t - 6) : 1;
+  const Params<T>& P = par[d.pset];
+  const bool joint = d.mode == JOINT;
+  const int nl = k < 6 ? k : 6;
+
+  for (int e = tid; e < N * 64; e += BLOCK) {
+    const int i = e >> 6, l = e & 63;
+    T vP = 1, vM = 1;
+    for (int bb = 0; bb < nl; ++bb)
+      if ((l >> bb) & 1) {
+        if (d.cls[bb] == CP) vP *= P.th[i][d.ev[bb]];
+        else if (d.cls[bb] == CM) vM *= P.th[i][d.ev[bb]];
+      }
+    LcP[e] = vP; LcM[e] = vM;
+    if (l < R) {
+      T uP = P.baseP[i], uM = P.baseM[i];
+      for (int bb = 6; bb < k; ++bb) {
+        const bool set = bb < t ? ((l >> (bb - 6)) & 1) : ((H >> (bb - t)) & 1u);
+        if (set) {
+          if (d.cls[bb] == CP) uP *= P.th[i][d.ev[bb]];
+          else if (d.cls[bb] == CM) uM *= P.th[i][d.ev[bb]];
+        }
+      }
+      UcP[e] = uP; UcM[e] = uM;
+    }
+  }
+  if (tid < 64) {
+    const int l = tid;
+    T a = 1, b = 1, ua = 1, ub = 1;
+    for (int bb = 0; bb < k; ++bb) {
+      const bool isA = joint ? d.cls[bb] == CP : bb != d.seedbit;
+      const bool isB = joint ? d.cls[bb] == CM : bb != d.seedbit;
+      if (bb < 6) {
+        if ((l >> bb) & 1) { if (isA) a *= P.dp[d.ev[bb]]; if (isB) b *= P.dm[d.ev[bb]]; }
+      } else {
+        const bool set = bb < t ? ((l >> (bb - 6)) & 1) : ((H >> (bb - t)) & 1u);
+        if (set && l < R) { if (isA) ua *= P.dp[d.ev[bb]]; if (isB) ub *= P.dm[d.ev[bb]]; }
+      }
+    }
+    LA[l] = a; LB[l] = b; UA[l] = ua; UB[l] = ub;
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < R; r += WAVES) {
+    const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+    if (xl >= nelem) continue;
+    const uint32_t x = (H << t) | xl;
+    const bool ss = seed_set(d, x);
+    const bool sbit = d.seedbit >= 0 && ((x >> d.seedbit) & 1u);
+    T dq = 0;
+    if (what <= KD_ADDQP) {
+      if (!joint) {
+        for (int i = 0; i < N; ++i)
+          if (d.bitP[i] < 0 || !((x >> d.bitP[i]) & 1u)) dq -= LcP[i * 64 + lane] * UcP[i * 64 + r];
+      } else if (ss) {
+        for (int i = 0; i < n; ++i) {
+          if (d.bitP[i] < 0 || !((x >> d.bitP[i]) & 1u)) dq -= LcP[i * 64 + lane] * UcP[i * 64 + r];
+          if (d.bitM[i] < 0 || !((x >> d.bitM[i]) & 1u)) dq -= LcM[i * 64 + lane] * UcM[i * 64 + r];
+        }
+      } else if (eq_noseed(d, x)) {
+        for (int i = 0; i < n; ++i)
+          if (d.bitP[i] < 0 || !((x >> d.bitP[i]) & 1u)) dq -= LcP[i * 64 + lane] * UcP[i * 64 + r];
+        dq -= LcP[n * 64 + lane] * UcP[n * 64 + r];
+      }
+    }
+    const T A = LA[lane] * UA[r], B = LB[lane] * UB[r];
+    T res;
+    if (what == KD_DQ) {
+      res = dq;
+    } else if (what == KD_LIDG) {
+      T dob;
+      if (d.obs == OBS_JOINT) dob = sbit ? A * P.dp[n] + B * P.dm[n] : A;
+      else if (d.obs == OBS_ONE) dob = 1;
+      else if (d.obs == OBS_MET) dob = sbit ? B * P.dm[n] : A;
+      else dob = dvec[base + x];
+      res = T(1) / (dob - dq);
+    } else if (what == KD_ADDQP) {
+      res = out[base + x] + dq * p[base + x];
+    } else if (what == KD_DP) {
+      res = (sbit ? A * P.dp[n] : A) * p[base + x];
+    } else {
+      res = (sbit ? B * P.dm[n] : T(0)) * p[base + x];
+    }
+    out[base + x] = res;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// marginal <-> joint transfers (likelihood.py:557-562, :573-575, :598-602, :617-618)
+// compatible joint states of part `part` (0: PT observed first, 1: MT first): all bits of
+// the observed tumour and the seeding bit set, the other tumour's bits free, ascending.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
+  uint32_t out = 0;
+  while (mask) {
+    const uint32_t low = mask & (0u - mask);
+    if (v & 1u) out |= low;
+    v >>= 1;
+    mask ^= low;
+  }
+  return out;
+}
+
+template <typename T>
+__device__ __forceinline__ T obs_const(const Desc& dj, const Params<T>& P, int part) {
+  // D_p (part 0) or D_m (part 1) on the compatible states: constant, every bit of the class is set
+  T c = part == 0 ? P.dp[dj.N - 1] : P.dm[dj.N - 1];
+  for (int b = 0; b < dj.k; ++b)
+    if (dj.cls[b] == (part == 0 ? CP : CM)) c *= (part == 0 ? P.dp[dj.ev[b]] : P.dm[dj.ev[b]]);
+  return c;
+}
+
+// rhsS[part problem] = [0 ; D * pi[compatible]]
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict__ pats,
+                                                       const Desc* __restrict__ dJ,
+                                                       const Desc* __restrict__ dS,
+                                                       const Params<T>* __restrict__ par,
+                                                       const T* __restrict__ pi, T* rhsS) {
+  const PatRec pr = pats[blockIdx.x];
+  const int part = blockIdx.y;
+  if (pr.j < 0 || pr.s[part] < 0) return;
+  const Desc& dj = dJ[pr.j];
+  const Desc& ds = dS[pr.s[part]];
+  const uint32_t fixed = (part == 0 ? dj.maskP : dj.maskM) | (1u << dj.seedbit);
+  const uint32_t free_ = part == 0 ? dj.maskM : dj.maskP;
+  const uint32_t half = 1u << (ds.k - 1);
+  const T c = obs_const(dj, par[PS_THETA], part);
+  for (uint32_t e = blockIdx.z * BLOCK + threadIdx.x; e < half; e += gridDim.z * BLOCK) {
+    const uint32_t x = pdep32(e, free_) | fixed;
+    rhsS[ds.off + e] = 0;
+    rhsS[ds.off + half + e] = c * pi[dj.off + x];
+  }
+}
+
+// rhsJ[compatible] += D * qS[upper half];  dots[pat][part] = <qS upper half, rhsS upper half>
+// one workgroup per patient; launched once per part (the two parts share the all-ones state)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict__ pats,
+                                                        const Desc* __restrict__ dJ,
+                                                        const Desc* __restrict__ dS,
+                                                        const Params<T>* __restrict__ par,
+                                                        const T* __restrict__ qS,
+                                                        const T* __restrict__ rhsS, T* rhsJ,
+                                                        T* dots, int part) {
+  __shared__ T red[BLOCK];
+  const PatRec pr = pats[blockIdx.x];
+  if (pr.j < 0 || pr.s[part] < 0) return;
+  const Desc& dj = dJ[pr.j];
+  const Desc& ds = dS[pr.s[part]];
+  const uint32_t fixed = (part == 0 ? dj.maskP : dj.maskM) | (1u << dj.seedbit);
+  const uint32_t free_ = part == 0 ? dj.maskM : dj.maskP;
+  const uint32_t half = 1u << (ds.k - 1);
+  const T c = obs_const(dj, par[PS_THETA], part);
+  T dot = 0;
+  for (uint32_t e = threadIdx.x; e < half; e += BLOCK) {
+    const uint32_t x = pdep32(e, free_) | fixed;
+    const T qv = qS[ds.off + half + e];
+    rhsJ[dj.off + x] += c * qv;
+    dot += qv * rhsS[ds.off + half + e];
+  }
+  red[threadIdx.x] = dot;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dots[2 * blockIdx.x + part] = red[0];
+}
+
+// e_0 right-hand sides of the unpaired patients' own single-tumour problems
+template <typename T>
+__global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS, T* rhsS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npat) return;
+  const PatRec pr = pats[i];
+  if (pr.kind <= 2 && pr.s[0] >= 0) rhsS[dS[pr.s[0]].off] = T(1);
+}
+
+// per patient: total marginal score, adjoint seeds 1/score for its single problems, log-prob
+template <typename T>
+__global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS,
+                        const Params<T>* __restrict__ par, const T* __restrict__ pS, T* seedS,
+                        double* lp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npat) return;
+  const PatRec pr = pats[i];
+  if (pr.kind == 4) return;
+  T full = 0;
+  for (int part = 0; part < 2; ++part)
+    if (pr.s[part] >= 0) {
+      const Desc& ds = dS[pr.s[part]];
+      full += pS[ds.off + (1ll << ds.k) - 1];
+    }
+  for (int part = 0; part < 2; ++part)
+    if (pr.s[part] >= 0) seedS[pr.s[part]] = T(1) / full;
+  double l = log((double)full);
+  if (pr.kind == 2) {   // likelihood.py:438: log(pTh[-1] * d_rates[-1]), last state has seeding set
+    const Desc& ds = dS[pr.s[0]];
+    const Params<T>& P = par[PS_THETA];
+    double dr = (double)P.dm[ds.N - 1];
+    for (int b = 0; b < ds.k; ++b)
+      if (b != ds.seedbit) dr *= (double)P.dm[ds.ev[b]];
+    l += log(dr);
+  }
+  lp[i] = l;
+}
+
+// ------------------------------------------------------------------------------------
+// gradient, stage 1 (joint spaces): class marginals of p (x) q on the seed = 1 half
+//   slot 0      W[S]   = - sum_T p[S|T] q[S|T]
+//   slot 1 + l  V_l[S] =   sum_T p[S|T] q[S|T|bit_l]      (bit_l not in S, else 0)
+// for class c in {P, M}: S over subsets of the class' bits, T over the other class' bits,
+// seeding bit set.  Layout at A + d.aoff: class P block [(kP+1)][2^kP], class M block
+// [(kM+1)][2^kM], then the eq block of k_eq_flows.  One workgroup per (problem, class);
+// each wave owns (slot, S) items and strides T across its lanes.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ long long class_block_size(int kc) { return (long long)(kc + 1) << kc; }
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_class_marg(const Desc* __restrict__ dJ,
+                                                      const T* __restrict__ p,
+                                                      const T* __restrict__ q, T* A) {
+  const Desc& d = dJ[blockIdx.x];
+  if (d.seedbit < 0) return;
+  const int c = blockIdx.y;
+  const uint32_t cm = c == 0 ? d.maskP : d.maskM;
+  const uint32_t om = c == 0 ? d.maskM : d.maskP;
+  const int kc = __popc(cm), ko = __popc(om);
+  const uint32_t sb = 1u << d.seedbit;
+  T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(__popc(d.maskP)));
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.z * BLOCK + threadIdx.x) >> 6;
+  const int nwave = gridDim.z * WAVES;
+  // lane part of T: the 6 lowest bits of the other class; remaining bits iterate uniformly
+  uint32_t lowm = 0, mm = om;
+  for (int i = 0; i < 6 && mm; ++i) { const uint32_t low = mm & (0u - mm); lowm |= low; mm ^= low; }
+  const uint32_t upm = om & ~lowm;
+  const int klow = __popc(lowm);
+  const bool lane_on = lane < (1 << klow);
+  const uint32_t tl = pdep32((uint32_t)lane, lowm);
+  const long long items = (long long)(kc + 1) << kc;
+  for (long long it = wave; it < items; it += nwave) {
+    const int slot = (int)(it >> kc);
+    const uint32_t s = (uint32_t)(it & ((1ll << kc) - 1));
+    const uint32_t S = pdep32(s, cm);
+    uint32_t bitl = 0;
+    bool valid = true;
+    if (slot > 0) {
+      bitl = pdep32(1u << (slot - 1), cm);
+      valid = (S & bitl) == 0;
+    }
+    T acc = 0;
+    if (valid && lane_on) {
+      uint32_t tu = 0;
+      const uint32_t cnt = 1u << (ko - klow);
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t x = S | tu | tl | sb;
+        acc += p[d.off + x] * q[d.off + (x | bitl)];
+        tu = ((tu | ~upm) + 1u) & upm;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[((long long)slot << kc) + s] = slot == 0 ? -acc : acc;
+  }
+}
+
+// eq block (seed = 0 states with PT == MT): subsets e of the paired events, x0 = both bits
+//   slot 0      -p[x0] q[x0]
+//   slot 1 + l   p[x0] q[x0 | pair_l]          (pair_l not in e)
+//   slot ke + 1  p[x0] q[x0 | seedbit]         (0 if seeding inactive)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_eq_flows(const Desc* __restrict__ dJ,
+                                                    const T* __restrict__ p,
+                                                    const T* __restrict__ q, T* A) {
+  const Desc& d = dJ[blockIdx.x];
+  const int ke = __popc(d.pairP);
+  T* out = A + d.aoff + class_block_size(__popc(d.maskP)) + class_block_size(__popc(d.maskM));
+  const long long items = (long long)(ke + 2) << ke;
+  const uint32_t pm3 = d.pairP | (d.pairP << 1);
+  for (long long it = threadIdx.x; it < items; it += BLOCK) {
+    const int slot = (int)(it >> ke);
+    const uint32_t e = (uint32_t)(it & ((1ll << ke) - 1));
+    const uint32_t xp = pdep32(e, d.pairP);
+    const uint32_t x0 = xp | (xp << 1);
+    T v;
+    if (slot == 0) {
+      v = -p[d.off + x0] * q[d.off + x0];
+    } else if (slot <= ke) {
+      const uint32_t bp = pdep32(1u << (slot - 1), d.pairP);
+      v = (x0 & bp) ? T(0) : p[d.off + x0] * q[d.off + (x0 | bp | (bp << 1))];
+    } else {
+      v = d.seedbit >= 0 ? p[d.off + x0] * q[d.off + (x0 | (1u << d.seedbit))] : T(0);
+    }
+    (void)pm3;
+    out[it] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// gradient, stage 2: flows of event i over one subset lattice -> row i of a G matrix.
+//   f(S)   = rate_i(S) * (A_slot(i)[S] + A_0[S])    if event i can still fire from S
+//   G[i,i] = sum_S f(S);  G[i, ev(l)] = sum_{S contains l} f(S);  kind M: G[i,n] = G[i,i]
+// kinds: GK_P / GK_M class marginals of a joint space, GK_E its eq block (rows 0..n),
+//        GK_S a single-tumour space with A formed on the fly from (p, q)
+//        (vanilla.py:328-393 in flow form).
+// grid = (problems, N); one workgroup per (problem, event).
+// ------------------------------------------------------------------------------------
+enum { GK_P = 0, GK_M = 1, GK_E = 2, GK_S = 3 };
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// grid = (problems, ceil(N / WAVES)); wave w of a workgroup owns event i = blockIdx.y * WAVES + w
+// and strides the subsets S across its lanes; all reductions are wave-level.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ descs,
+                                                     const Params<T>* __restrict__ par,
+                                                     const T* __restrict__ A,
+                                                     const T* __restrict__ p,
+                                                     const T* __restrict__ q, T* G, int kind,
+                                                     int maxhi) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][64]
+  T* rowbuf = Tlo + WAVES * 64;                 // [WAVES][32]
+  T* hiacc = rowbuf + WAVES * 32;               // [WAVES][maxhi][64]
+  __shared__ int lev[32];                       // event of local bit l
+  const Desc& d = descs[blockIdx.x];
+  const int N = d.N, n = N - 1;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int i = blockIdx.y * WAVES + w;
+  const Params<T>& P = par[d.pset];
+
+  uint32_t cm;
+  if (kind == GK_P) cm = d.maskP; else if (kind == GK_M) cm = d.maskM;
+  else if (kind == GK_E) cm = d.pairP; else cm = (1u << d.k) - 1u;
+  const int kc = __popc(cm);
+  if (tid == 0) {
+    uint32_t m = cm; int l = 0;
+    while (m) { const int b = __ffs(m) - 1; lev[l] = d.ev[b]; ++l; m &= m - 1; }
+  }
+  __syncthreads();
+  if (i >= N) return;
+  T* row = G + ((long long)blockIdx.x * N + i) * N;
+  T* rb = rowbuf + w * 32;
+  if (lane < 32) rb[lane] = 0;
+
+  bool rowvalid = true;
+  T base = kind == GK_M ? P.baseM[i] : P.baseP[i];
+  if ((kind == GK_P || kind == GK_M) && (i >= n || d.seedbit < 0)) rowvalid = false;
+  if (kind == GK_E && d.mode != JOINT) rowvalid = false;
+  int slot = -1;                                // local slot of event i; kc = extra always-free slot
+  if (kind == GK_E && i == n) slot = kc;
+  else for (int l = 0; l < kc; ++l) if (lev[l] == i) slot = l;
+
+  if (rowvalid) {
+    const int klo = kc < 6 ? kc : 6;
+    const int nhi = kc - klo;
+    {
+      T v = 1;
+      for (int l = 0; l < klo; ++l) if ((lane >> l) & 1) v *= P.th[i][lev[l]];
+      Tlo[w * 64 + lane] = v;
+    }
+    T* ha = hiacc + (long long)w * maxhi * 64;
+    for (int l = 0; l < nhi; ++l) ha[l * 64 + lane] = 0;
+    const T* Ab = nullptr;
+    if (kind != GK_S) {
+      long long o = d.aoff;
+      if (kind != GK_P) o += class_block_size(__popc(d.maskP));
+      if (kind == GK_E) o += class_block_size(__popc(d.maskM));
+      Ab = A + o;
+    }
+    const long long nS = 1ll << kc;
+    T tot = 0;
+    for (long long S0 = 0; S0 < nS; S0 += 64) {
+      const long long S = S0 + lane;
+      const uint32_t s = (uint32_t)S;
+      T urate = base;                            // wave-uniform part of the rate
+      for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= P.th[i][lev[l]];
+      T f = 0;
+      const bool blocked = slot >= 0 && slot < kc && ((s >> slot) & 1u);
+      if (S < nS && !blocked) {
+        T a0, a1 = 0;
+        if (kind == GK_S) {
+          const T pv = p[d.off + s];
+          a0 = -pv * q[d.off + s];
+          if (slot >= 0) a1 = pv * q[d.off + (s | (1u << slot))];
+        } else {
+          a0 = Ab[S];
+          if (slot >= 0) a1 = Ab[((long long)(slot + 1) << kc) + S];
+        }
+        f = urate * Tlo[w * 64 + (s & 63u)] * (a0 + a1);
+      }
+      tot += f;
+      for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
+    }
+    const T total = wave_sum(tot);
+    if (lane == 0) { rb[i] = total; if (kind == GK_M) rb[n] = total; }
+    for (int l = 0; l < kc; ++l) {
+      const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
+      const T m = wave_sum(v);
+      if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
+    }
+  }
+  if (lane < N) row[lane] = rb[lane];
+}
+
+// ------------------------------------------------------------------------------------
+// weighted bit marginals for the observation-rate gradients
+//   out[prob][0][b] = sum_{x contains b} q p W_A(x),  out[prob][1][b] likewise with W_B
+// JOINT: W_A = D_p, W_B = D_m (x_partial_D_y, likelihood.py:204-228);
+// SINGLE/OBS_MET: W_A = d_p part, W_B = d_m part of scal_d_pt (vanilla.py:125-203).
+// One workgroup per tile, atomics per (tile, bit).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_bit_marg(const Desc* __restrict__ descs,
+                                                    const int2* __restrict__ map,
+                                                    const Params<T>* __restrict__ par,
+                                                    const T* __restrict__ p,
+                                                    const T* __restrict__ q, T* out) {
+  // per-wave partials: [WAVES][2 weights][13] = total + marginals of the 12 in-tile bits
+  __shared__ T part[WAVES][2][16];
+  const Desc& d = descs[map[blockIdx.x].x];
+  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  const int k = d.k, n = d.N - 1;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t;
+  const Params<T>& P = par[d.pset];
+  const bool joint = d.mode == JOINT;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  constexpr int NJ = (1 << TB) / BLOCK;          // 16 strided states per thread: bits 8..11 = j
+  T tot[2] = {0, 0};
+  T mj[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t xl = (uint32_t)j * BLOCK + tid;
+    if (xl < nelem) {
+      const uint32_t x = (H << t) | xl;
+      T a = 1, b = 1;
+      for (int bb = 0; bb < k; ++bb)
+        if ((x >> bb) & 1u) {
+          if (joint ? d.cls[bb] == CP : bb != d.seedbit) a *= P.dp[d.ev[bb]];
+          if (joint ? d.cls[bb] == CM : bb != d.seedbit) b *= P.dm[d.ev[bb]];
+        }
+      const bool sbit = d.seedbit >= 0 && ((x >> d.seedbit) & 1u);
+      T wA, wB;
+      if (joint) { wA = sbit ? a * P.dp[n] : a; wB = sbit ? b * P.dm[n] : T(0); }
+      else { wA = sbit ? T(0) : a; wB = sbit ? b * P.dm[n] : T(0); }
+      const T pq = p[d.off + x] * q[d.off + x];
+      const T vA = pq * wA, vB = pq * wB;
+      tot[0] += vA; tot[1] += vB;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) if ((j >> l) & 1) { mj[0][l] += vA; mj[1][l] += vB; }
+    }
+  }
+#pragma unroll
+  for (int ww = 0; ww < 2; ++ww) {
+    const T s = wave_sum(tot[ww]);
+    if (lane == 0) part[w][ww][12] = s;
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+      const T m = wave_sum(((lane >> l) & 1) ? tot[ww] : T(0));
+      if (lane == 0) part[w][ww][l] = m;
+    }
+    if (lane == 0) { part[w][ww][6] = (w & 1) ? s : T(0); part[w][ww][7] = (w & 2) ? s : T(0); }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const T m = wave_sum(mj[ww][l]);
+      if (lane == 0) part[w][ww][8 + l] = m;
+    }
+  }
+  __syncthreads();
+  T* o = out + (long long)map[blockIdx.x].x * 64;
+  if (tid < 2 * 32) {
+    const int ww = tid >> 5, b = tid & 31;
+    if (b < k) {
+      T m = 0;
+      if (b < t) { for (int v = 0; v < WAVES; ++v) m += part[v][ww][b]; }
+      else if ((H >> (b - t)) & 1u) { for (int v = 0; v < WAVES; ++v) m += part[v][ww][12]; }
+      if (m != T(0)) atomicAdd(&o[ww * 32 + b], m);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// per-patient assembly (likelihood.py:441-512, :623-731) and cohort reduction
+// out[pat] = [ lp, G[N][N], d_dp[N], d_dm[N] ]
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_finalize(const PatRec* __restrict__ pats,
+                                                    const Desc* __restrict__ dJ,
+                                                    const Desc* __restrict__ dS,
+                                                    const Params<T>* __restrict__ par,
+                                                    const T* __restrict__ GS,
+                                                    const T* __restrict__ GJ, long long gj_stride,
+                                                    const T* __restrict__ dots,
+                                                    const T* __restrict__ bmJ,
+                                                    const T* __restrict__ bmS,
+                                                    const double* __restrict__ lp, double* out,
+                                                    int N, int with_grad) {
+  const PatRec pr = pats[blockIdx.x];
+  const int n = N - 1;
+  const int stride = 1 + N * N + 2 * N;
+  double* o = out + (long long)blockIdx.x * stride;
+  const int tid = threadIdx.x;
+  const Params<T>& P0 = par[PS_THETA];
+  if (pr.kind == 4) {                              // _grad_prim_obs_az, likelihood.py:464-478
+    double s = 0;
+    for (int i = 0; i < N; ++i) s += (double)P0.th[i][i];
+    for (int e = tid; e < stride; e += BLOCK) o[e] = 0;
+    __syncthreads();
+    if (tid == 0) o[0] = -log1p(s);
+    if (with_grad && tid < N) o[1 + tid * N + tid] = -(double)P0.th[tid][tid] / (1.0 + s);
+    return;
+  }
+  if (tid == 0) o[0] = lp[blockIdx.x];
+  if (!with_grad) return;
+  // theta gradient
+  for (int e = tid; e < N * N; e += BLOCK) {
+    const int i = e / N, j = e % N;
+    double g = 0;
+    for (int part = 0; part < 2; ++part)
+      if (pr.s[part] >= 0) {
+        const bool prim_space = dS[pr.s[part]].pset == PS_PRIM;
+        if (!(prim_space && j == n && i < n)) g += (double)GS[(long long)pr.s[part] * N * N + e];
+      }
+    if (pr.j >= 0)
+      for (int kd = 0; kd < 3; ++kd) g += (double)GJ[kd * gj_stride + (long long)pr.j * N * N + e];
+    o[1 + e] = g;
+  }
+  // observation-rate gradients
+  for (int i = tid; i < N; i += BLOCK) {
+    double gp = 0, gm = 0;
+    for (int part = 0; part < 2; ++part) {
+      if (pr.s[part] < 0) continue;
+      const Desc& ds = dS[pr.s[part]];
+      const T* g = GS + (long long)pr.s[part] * N * N;
+      double dd = 0;                               // d_diag[i] = -sum_{r != i} val[r, i], vanilla.py:392
+      for (int r = 0; r < N; ++r) if (r != i) dd -= (double)g[r * N + i];
+      if (pr.kind == 3) {
+        const Desc& dj = dJ[pr.j];
+        const double dot = (double)dots[2 * blockIdx.x + part];
+        if (part == 0) { gm += dd; if (i == n || dj.bitP[i] >= 0) gp += dot; }
+        else           { gp += dd; if (i == n || dj.bitM[i] >= 0) gm += dot; }
+      } else if (pr.kind == 2) {                   // _grad_met_obs, likelihood.py:481-512
+        const T* bm = bmS + (long long)pr.s[0] * 64;
+        const int b = ds.bitP[i];
+        if (b >= 0) {
+          if (b != ds.seedbit) gp -= (double)bm[b];
+          gm += 1.0 - (double)bm[32 + b];
+        }
+      } else {
+        gp += dd;                                  // _grad_prim_obs, likelihood.py:441-461
+      }
+    }
+    if (pr.kind == 3) {                            // minus x_partial_D_y(q_J, pi), likelihood.py:536,694-695
+      const Desc& dj = dJ[pr.j];
+      const T* bm = bmJ + (long long)pr.j * 64;
+      const int bp = i == n ? dj.seedbit : dj.bitP[i];
+      const int bq = i == n ? dj.seedbit : dj.bitM[i];
+      if (bp >= 0) gp -= (double)bm[bp];
+      if (bq >= 0) gm -= (double)bm[32 + bq];
+    }
+    o[1 + N * N + i] = gp;
+    o[1 + N * N + N + i] = gm;
+  }
+}
+
+// sums[cls][e] = sum over patients of class cls (0: type != 0, 1: type 0) of out[pat][e]
+__global__ __launch_bounds__(BLOCK) void k_reduce(const PatRec* __restrict__ pats, int npat,
+                                                  const double* __restrict__ out, int stride,
+                                                  double* sums) {
+  __shared__ double red[BLOCK];
+  const int e = blockIdx.x, cls = blockIdx.y;
+  double acc = 0;
+  for (int i = threadIdx.x; i < npat; i += BLOCK) {
+    const int kd = pats[i].kind;
+    const int c = (kd == 0 || kd == 4) ? 1 : 0;
+    if (c == cls) acc += out[(long long)i * stride + e];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[cls * stride + e] += red[0];
+}
+
+}  // namespace mmhn

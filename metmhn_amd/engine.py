@@ -1,0 +1,191 @@
+"""Python handle on the native engine (one engine = one GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import f64p, i8p, i64p
+
+F64, F32 = 0, 1
+
+
+def _f(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(f64p)
+
+
+def _s(a):
+    a = np.ascontiguousarray(np.asarray(a).astype(np.int8))
+    return a, a.ctypes.data_as(i8p)
+
+
+class Engine:
+    """Owns a mmhn_handle.  `n_mut` mutations -> N = n_mut + 1 events incl. seeding."""
+
+    def __init__(self, n_mut: int, device: int = 0, dtype: str = "f64", workspace_bytes: int | None = None):
+        self.lib = _lib.load()
+        self.n = int(n_mut)
+        self.N = self.n + 1
+        self.dtype = dtype
+        h = C.c_void_p()
+        _lib.check(self.lib.mmhn_create(int(device), self.n, F64 if dtype == "f64" else F32, C.byref(h)))
+        self.h = h
+        self.n_pat = 0
+        if workspace_bytes:
+            _lib.check(self.lib.mmhn_set_workspace_limit(self.h, int(workspace_bytes)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mmhn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- cohort objective
+    def set_cohort(self, dat):
+        dat = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+        if dat.ndim != 2 or dat.shape[1] != 2 * self.n + 3:
+            raise ValueError(f"dat must be [n_pat, {2 * self.n + 3}]")
+        _lib.check(self.lib.mmhn_set_cohort(self.h, dat.ctypes.data_as(i8p), dat.shape[0], dat.shape[1]))
+        self.n_pat = dat.shape[0]
+
+    def _params(self, log_theta, log_d_p, log_d_m):
+        lt, ltp = _f(log_theta)
+        dp, dpp = _f(log_d_p)
+        dm, dmp = _f(log_d_m)
+        if lt.shape != (self.N, self.N) or dp.shape != (self.N,) or dm.shape != (self.N,):
+            raise ValueError("parameter shapes do not match n_mut")
+        return (lt, dp, dm), (ltp, dpp, dmp)
+
+    def score(self, log_theta, log_d_p, log_d_m, perc_met):
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        out = C.c_double()
+        _lib.check(self.lib.mmhn_score(self.h, a, b, c, float(perc_met), C.byref(out)))
+        return out.value
+
+    def score_and_grad(self, log_theta, log_d_p, log_d_m, perc_met):
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        out = C.c_double()
+        g = np.zeros((self.N, self.N))
+        gp = np.zeros(self.N)
+        gm = np.zeros(self.N)
+        _lib.check(self.lib.mmhn_score_and_grad(self.h, a, b, c, float(perc_met), C.byref(out),
+                                                 g.ctypes.data_as(f64p), gp.ctypes.data_as(f64p),
+                                                 gm.ctypes.data_as(f64p)))
+        return out.value, g, gp, gm
+
+    def cohort_sums(self, log_theta, log_d_p, log_d_m, with_grad=True):
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        sums = np.zeros(4 + 2 * self.N * self.N + 3 * self.N)
+        _lib.check(self.lib.mmhn_cohort_sums(self.h, a, b, c, int(bool(with_grad)), sums.ctypes.data_as(f64p)))
+        return sums
+
+    def patient_grads(self, log_theta, log_d_p, log_d_m, with_grad=True):
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        P, N = self.n_pat, self.N
+        lp = np.zeros(P)
+        if not with_grad:
+            _lib.check(self.lib.mmhn_patient_grads(self.h, a, b, c, lp.ctypes.data_as(f64p), None, None, None))
+            return lp
+        g, gp, gm = np.zeros((P, N, N)), np.zeros((P, N)), np.zeros((P, N))
+        _lib.check(self.lib.mmhn_patient_grads(self.h, a, b, c, lp.ctypes.data_as(f64p), g.ctypes.data_as(f64p),
+                                               gp.ctypes.data_as(f64p), gm.ctypes.data_as(f64p)))
+        return lp, g, gp, gm
+
+    # ---- joint primitives
+    def kronvec(self, log_theta, p, state, diag=True, transpose=False):
+        lt, ltp = _f(log_theta); pv, pp = _f(p); st, sp = _s(state)
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_kronvec(self.h, ltp, sp, pp, y.ctypes.data_as(f64p), int(diag), int(transpose)))
+        return y
+
+    def kron_diag(self, log_theta, state):
+        lt, ltp = _f(log_theta); st, sp = _s(state)
+        y = np.zeros(2 ** int(st.sum()))
+        _lib.check(self.lib.mmhn_kron_diag(self.h, ltp, sp, y.ctypes.data_as(f64p)))
+        return y
+
+    def diag_scal(self, log_d, state, p, which):
+        d, dp_ = _f(log_d); pv, pp = _f(p); st, sp = _s(state)
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_diag_scal(self.h, dp_, sp, pp, y.ctypes.data_as(f64p), int(which)))
+        return y
+
+    def obs_indices(self, state, pt_first):
+        st, sp = _s(state)
+        n = (st.shape[0] - 1) // 2
+        free = int(st[1:2 * n:2].sum()) if pt_first else int(st[0:2 * n:2].sum())
+        idx = np.zeros(2 ** free, dtype=np.int64)
+        cnt = C.c_int64()
+        _lib.check(self.lib.mmhn_obs_states(self.h, sp, int(bool(pt_first)), idx.ctypes.data_as(i64p), C.byref(cnt)))
+        return idx[:cnt.value]
+
+    def resolvent(self, log_theta, log_d_p, log_d_m, x, state, transpose=False):
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        xv, xp = _f(x); st, sp = _s(state)
+        y = np.zeros_like(xv)
+        _lib.check(self.lib.mmhn_resolvent(self.h, a, b, c, sp, xp, y.ctypes.data_as(f64p), int(transpose)))
+        return y
+
+    def x_partial_Q_y(self, log_theta, x, y, state):
+        lt, ltp = _f(log_theta); xv, xp = _f(x); yv, yp = _f(y); st, sp = _s(state)
+        G = np.zeros((self.N, self.N))
+        _lib.check(self.lib.mmhn_x_partial_Q_y(self.h, ltp, sp, xp, yp, G.ctypes.data_as(f64p)))
+        return G
+
+    def x_partial_D_y(self, log_d_p, log_d_m, state, x, y):
+        a, ap = _f(log_d_p); b, bp = _f(log_d_m); xv, xp = _f(x); yv, yp = _f(y); st, sp = _s(state)
+        ddp, ddm = np.zeros(self.N), np.zeros(self.N)
+        _lib.check(self.lib.mmhn_x_partial_D_y(self.h, ap, bp, sp, xp, yp, ddp.ctypes.data_as(f64p),
+                                               ddm.ctypes.data_as(f64p)))
+        return ddp, ddm
+
+    # ---- single-tumour primitives
+    def v_kronvec(self, log_theta, p, state, diag=True, transpose=False):
+        lt, ltp = _f(log_theta); pv, pp = _f(p); st, sp = _s(state)
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_v_kronvec(self.h, ltp, sp, pp, y.ctypes.data_as(f64p), int(diag), int(transpose)))
+        return y
+
+    def v_resolvent(self, log_theta, x, state, d_rates=None, transpose=False):
+        lt, ltp = _f(log_theta); xv, xp = _f(x); st, sp = _s(state)
+        y = np.zeros_like(xv)
+        if d_rates is None or np.isscalar(d_rates):
+            if d_rates is not None and float(d_rates) != 1.0:
+                d_rates = np.full_like(xv, float(d_rates))
+            else:
+                d_rates = None
+        dr = None
+        if d_rates is not None:
+            dkeep, dr = _f(d_rates)
+        _lib.check(self.lib.mmhn_v_resolvent(self.h, ltp, sp, dr, xp, y.ctypes.data_as(f64p), int(transpose)))
+        return y
+
+    def v_x_partial_Q_y(self, log_theta, x, y, state):
+        lt, ltp = _f(log_theta); xv, xp = _f(x); yv, yp = _f(y); st, sp = _s(state)
+        G, dd = np.zeros((self.N, self.N)), np.zeros(self.N)
+        _lib.check(self.lib.mmhn_v_x_partial_Q_y(self.h, ltp, sp, xp, yp, G.ctypes.data_as(f64p),
+                                                 dd.ctypes.data_as(f64p)))
+        return G, dd
+
+    # ---- measurement
+    def bench_kronvec(self, log_theta, state, batch, iters, transpose=False, jacobi=False):
+        lt, ltp = _f(log_theta); st, sp = _s(state)
+        ms = C.c_double()
+        _lib.check(self.lib.mmhn_bench_kronvec(self.h, ltp, sp, int(batch), int(iters), int(transpose), int(jacobi),
+                                               C.byref(ms)))
+        return ms.value
+
+    def counters(self):
+        c = _lib.Counters()
+        _lib.check(self.lib.mmhn_get_counters(self.h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in c._fields_}
+
+    def reset_counters(self):
+        _lib.check(self.lib.mmhn_reset_counters(self.h))

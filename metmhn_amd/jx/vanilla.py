@@ -1,0 +1,25 @@
+"""metmhn/jx/vanilla.py entry points (single-tumour MHN, state of length n+1)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import engine
+
+
+def _n(state):
+    return np.asarray(state).shape[0] - 1
+
+
+def kronvec(log_theta, p, state, diag: bool = True, transpose: bool = False):
+    """vanilla.py:78-106."""
+    return engine(_n(state)).v_kronvec(log_theta, p, state, diag, transpose)
+
+
+def R_inv_vec(log_theta, x, state, d_rates=1, transpose: bool = False):
+    """vanilla.py:269-305."""
+    return engine(_n(state)).v_resolvent(log_theta, x, state, d_rates, transpose)
+
+
+def x_partial_Q_y(log_theta, x, y, state):
+    """vanilla.py:328-393: (val, d_diag)."""
+    return engine(_n(state)).v_x_partial_Q_y(log_theta, x, y, state)

@@ -1,0 +1,148 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/metmhn_amd.h
+declares; host logic (sharding, all-reduce combination, penalties, synthetic generators)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from metmhn_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "metmhn_amd.h")).read()
+    declared = set(re.findall(r"\b(mmhn_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    bound = set(_lib.SIGNATURES) | set(_lib.OTHER_SYMBOLS)
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from metmhn_amd import Engine
+    with pytest.raises(RuntimeError, match="no .*device|no HIP device"):
+        Engine(3)
+
+
+def test_penalties_match_oracle(golden):
+    import metmhn_amd.regularized_optimization as ro
+    g = golden("cohorts")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        lt, dp, dm = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"]
+        params = np.concatenate((lt.flatten(), dp, dm))
+        pen, pen_ = ro.symmetric_penal(params, lt.shape[0])
+        np.testing.assert_allclose(pen, g[pre + "pen"], rtol=1e-13)
+        np.testing.assert_allclose(pen_, g[pre + "pen_grad"], rtol=1e-13, atol=1e-15)
+
+
+def _oracle_sums(lt, dp, dm, dat):
+    """What mmhn_cohort_sums returns, computed by the CPU oracle (test infrastructure)."""
+    from oracle import metmhn_oracle as O
+    N = lt.shape[0]
+    s = np.zeros(4 + 2 * N * N + 3 * N)
+    g_em, g_nm = np.zeros((N, N)), np.zeros((N, N))
+    p_em, p_nm, m_em = np.zeros(N), np.zeros(N), np.zeros(N)
+    for row in dat:
+        lp, g, a, b, is0 = O.patient_grad(lt, dp, dm, row)
+        if is0:
+            s[1] += lp; g_nm += g; p_nm += a
+        else:
+            s[0] += lp; g_em += g; p_em += a; m_em += b
+    s[2] = dat[:, -3].sum()
+    s[3] = dat.shape[0]
+    s[4:] = np.concatenate((g_em.ravel(), g_nm.ravel(), p_em, p_nm, m_em))
+    return s
+
+
+def test_combine_sums_matches_reference_weighting(golden):
+    from metmhn_amd import distributed as D
+    g = golden("cohorts")
+    for c in (0, 1, 2):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        s, gth, gdp, gdm = D.combine_sums(_oracle_sums(lt, dp, dm, dat), lt.shape[0], float(g[pre + "perc_met"]))
+        np.testing.assert_allclose(s, g[pre + "score"], rtol=1e-12)
+        np.testing.assert_allclose(gth, g[pre + "d_th"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(gdp, g[pre + "d_dp"], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(gdm, g[pre + "d_dm"], rtol=1e-10, atol=1e-13)
+
+
+def test_shard_rows_partition():
+    from metmhn_amd import distributed as D, synthetic
+    dat = synthetic.mixed_cohort(6, 101, seed=1)
+    for w in (1, 2, 3, 8):
+        parts = D.shard_rows(dat, w)
+        allr = np.sort(np.concatenate(parts))
+        assert np.array_equal(allr, np.arange(101))
+        cost = D.patient_cost(dat)
+        loads = np.array([cost[p].sum() for p in parts])
+        assert loads.max() <= loads.mean() + cost.max() + 1e-9          # LPT bound
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metmhn_amd import distributed as D
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cohorts.npz"))
+    lt, dp, dm, dat = g["c1_log_theta"], g["c1_log_d_p"], g["c1_log_d_m"], g["c1_dat"]
+    rows = D.shard_rows(dat, world)[rank]
+    local = _oracle_sums(lt, dp, dm, dat[rows])           # stands in for Engine.cohort_sums of this rank's shard
+    tot = D.allreduce_sums(local)
+    res = D.combine_sums(tot, lt.shape[0], float(g["c1_perc_met"]))
+    if rank == 0:
+        q.put([np.asarray(r) for r in res])
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_reproduces_full_cohort(golden):
+    """world_size-2 patient sharding + one all-reduce == the single-process result."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = golden("cohorts")
+    np.testing.assert_allclose(res[0], g["c1_score"], rtol=1e-12)
+    np.testing.assert_allclose(res[1], g["c1_d_th"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(res[2], g["c1_d_dp"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(res[3], g["c1_d_dm"], rtol=1e-10, atol=1e-13)
+
+
+def test_synthetic_generators():
+    from metmhn_amd import synthetic
+    d = synthetic.full_k_cohort(12, 50)
+    assert d.shape == (50, 27) and d.dtype == np.int8
+    assert (d[:, :-2].sum(axis=1) == 12).all() and (d[:, -1] == 3).all() and set(np.unique(d[:, -2])) <= {0, 1, 2}
+    lt, dp, dm = synthetic.random_params(12)
+    assert lt.shape == (13, 13) and dp.shape == (13,)
+    m = synthetic.mixed_cohort(5, 200, seed=2)
+    assert set(np.unique(m[:, -1])) == {0, 1, 2, 3}
+    assert (m[m[:, -1] == 0, -3] == 0).all() and (m[m[:, -1] != 0, -3] == 1).all()

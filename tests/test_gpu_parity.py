@@ -1,0 +1,204 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors of the reference and
+with the CPU oracle on seeded inputs.  fp64 tolerance: 1e-6 relative (BASELINE.json
+north_star); indices bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # north_star tolerance for fp64 likelihoods / gradients
+TIGHT = dict(rtol=1e-9, atol=1e-11)   # what the fp64 kernels actually deliver on small cases
+
+
+def _cases(g):
+    return range(int(g["n_cases"]))
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from metmhn_amd import Engine
+    cache = {}
+
+    def get(n):
+        if n not in cache:
+            cache[n] = Engine(n)
+        return cache[n]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def test_joint_primitives_golden(golden, engines):
+    g = golden("primitives")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"]
+        st, p, x = g[pre + "state"], g[pre + "p"], g[pre + "x"]
+        n = (st.shape[0] - 1) // 2
+        k = int(st.sum())
+        e = engines(n)
+        for dg in (0, 1):
+            for tr in (0, 1):
+                np.testing.assert_allclose(e.kronvec(lt, p, st, bool(dg), bool(tr)), g[pre + f"kv_d{dg}_t{tr}"],
+                                           err_msg=f"case {c} kronvec d{dg} t{tr}", **TIGHT)
+        np.testing.assert_allclose(e.kron_diag(lt, st), g[pre + "kron_diag"], err_msg=f"case {c} kron_diag", **TIGHT)
+        if st[-1] == 1:
+            np.testing.assert_allclose(e.diag_scal(dp, st, p, 0), g[pre + "dsp"], **TIGHT)
+            np.testing.assert_allclose(e.diag_scal(dm, st, p, 1), g[pre + "dsm"], **TIGHT)
+            for name, pf in (("pf", True), ("mf", False)):
+                assert np.array_equal(e.obs_indices(st, pf), g[pre + "idx_" + name]), f"case {c} obs {name}"
+            if k >= 2:
+                for tr in (0, 1):
+                    np.testing.assert_allclose(e.resolvent(lt, dp, dm, x, st, bool(tr)), g[pre + f"R_t{tr}"],
+                                               err_msg=f"case {c} resolvent t{tr}", **TIGHT)
+                np.testing.assert_allclose(e.x_partial_Q_y(lt, x, p, st), g[pre + "xQy"],
+                                           err_msg=f"case {c} xQy", **TIGHT)
+                a, b = e.x_partial_D_y(dp, dm, st, x, p)
+                np.testing.assert_allclose(a, g[pre + "xDy_dp"], err_msg=f"case {c} xDy dp", **TIGHT)
+                np.testing.assert_allclose(b, g[pre + "xDy_dm"], err_msg=f"case {c} xDy dm", **TIGHT)
+
+
+def test_single_primitives_golden(golden, engines):
+    g = golden("vanilla")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, st, p, x, dr = g[pre + "log_theta"], g[pre + "state"], g[pre + "p"], g[pre + "x"], g[pre + "d_rates"]
+        e = engines(st.shape[0] - 1)
+        for dg in (0, 1):
+            for tr in (0, 1):
+                np.testing.assert_allclose(e.v_kronvec(lt, p, st, bool(dg), bool(tr)), g[pre + f"kv_d{dg}_t{tr}"],
+                                           err_msg=f"case {c} v_kronvec d{dg} t{tr}", **TIGHT)
+        for tr in (0, 1):
+            np.testing.assert_allclose(e.v_resolvent(lt, x, st, None, bool(tr)), g[pre + f"R1_t{tr}"], **TIGHT)
+            np.testing.assert_allclose(e.v_resolvent(lt, x, st, dr, bool(tr)), g[pre + f"Rd_t{tr}"], **TIGHT)
+        a, b = e.v_x_partial_Q_y(lt, x, p, st)
+        np.testing.assert_allclose(a, g[pre + "xQy"], err_msg=f"case {c} v_xQy", **TIGHT)
+        np.testing.assert_allclose(b, g[pre + "xQy_ddiag"], **TIGHT)
+
+
+def test_reference_module_surface(golden):
+    """The metmhn.jx-style mirrors take the reference's argument orders."""
+    from metmhn_amd.jx import kronvec as K, likelihood as L, vanilla as V
+    g = golden("primitives")
+    pre = "c5_"
+    lt, dp, dm, st, p, x = (g[pre + s] for s in ("log_theta", "log_d_p", "log_d_m", "state", "p", "x"))
+    k = int(st.sum())
+    np.testing.assert_allclose(K.kronvec(lt, p, st, diag=False, transpose=True), g[pre + "kv_d0_t1"], **TIGHT)
+    np.testing.assert_allclose(K.kron_diag(lt, st, k), g[pre + "kron_diag"], **TIGHT)
+    np.testing.assert_allclose(K.diag_scal_p(dp, st, p), g[pre + "dsp"], **TIGHT)
+    assert np.array_equal(K.obs_states(k, st, True), g[pre + "obs_pf"])
+    np.testing.assert_allclose(L.R_i_inv_vec(lt, dp, dm, x, st, k, transpose=True), g[pre + "R_t1"], **TIGHT)
+    a, b = L.x_partial_D_y(dm, dp, st, x, p)           # reference order: (log_d_m, log_d_p, ...)
+    np.testing.assert_allclose(a, g[pre + "xDy_dp"], **TIGHT)
+    np.testing.assert_allclose(b, g[pre + "xDy_dm"], **TIGHT)
+    gv = golden("vanilla")
+    np.testing.assert_allclose(V.R_inv_vec(gv["c3_log_theta"], gv["c3_x"], gv["c3_state"], 1, True), gv["c3_R1_t1"],
+                               **TIGHT)
+
+
+def test_patients_golden(golden, engines):
+    g = golden("patients")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        e = engines((dat.shape[1] - 3) // 2)
+        e.set_cohort(dat)
+        lp, gth, gdp, gdm = e.patient_grads(lt, dp, dm)
+        for r in range(dat.shape[0]):
+            msg = f"set {c} row {r} {dat[r]}"
+            np.testing.assert_allclose(lp[r], g[pre + "lp_grad"][r], err_msg=msg, **TIGHT)
+            np.testing.assert_allclose(gth[r], g[pre + "d_th"][r], err_msg=msg, **TIGHT)
+            np.testing.assert_allclose(gdp[r], g[pre + "d_dp"][r], err_msg=msg, **TIGHT)
+            np.testing.assert_allclose(gdm[r], g[pre + "d_dm"][r], err_msg=msg, **TIGHT)
+        lp_only = e.patient_grads(lt, dp, dm, with_grad=False)
+        np.testing.assert_allclose(lp_only, g[pre + "lp_score"], **TIGHT)
+
+
+def test_cohorts_golden(golden):
+    import metmhn_amd.regularized_optimization as ro
+    g = golden("cohorts")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        pm, lam = float(g[pre + "perc_met"]), float(g[pre + "lam"])
+        s, gth, gdp, gdm = ro.score_and_grad(lt, dp, dm, dat, pm)
+        np.testing.assert_allclose(s, g[pre + "score"], rtol=RTOL, err_msg=f"cohort {c}")
+        np.testing.assert_allclose(s, g[pre + "score"], **TIGHT)
+        np.testing.assert_allclose(ro.score(lt, dp, dm, dat, pm), g[pre + "score_only"], **TIGHT)
+        np.testing.assert_allclose(gth, g[pre + "d_th"], **TIGHT)
+        np.testing.assert_allclose(gdp, g[pre + "d_dp"], **TIGHT)
+        np.testing.assert_allclose(gdm, g[pre + "d_dm"], **TIGHT)
+        params = np.concatenate((lt.flatten(), dp, dm))
+        v, gr = ro.score_and_grad_reg(params, dat, pm, ro.symmetric_penal, lam)
+        np.testing.assert_allclose(v, g[pre + "reg_value"], **TIGHT)
+        np.testing.assert_allclose(gr, g[pre + "reg_grad"], **TIGHT)
+        np.testing.assert_allclose(ro.score_reg(params, dat, pm, ro.symmetric_penal, lam), g[pre + "reg_value_only"],
+                                   **TIGHT)
+
+
+def test_multi_tile_against_oracle(engines):
+    """k = 14 > tile bits: neighbour tiles, several workgroups per vector."""
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import synthetic
+    n = 7
+    lt, dp, dm = synthetic.random_params(n, seed=11)
+    st = np.ones(2 * n + 1, dtype=np.int8)
+    st[3] = 0
+    k = int(st.sum())
+    rng = np.random.default_rng(0)
+    p, x = rng.normal(size=2 ** k), rng.normal(size=2 ** k)
+    e = engines(n)
+    for tr in (False, True):
+        np.testing.assert_allclose(e.kronvec(lt, p, st, True, tr), O.kronvec(lt, p, st, True, tr), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(e.resolvent(lt, dp, dm, x, st, False), O.R_i_inv_vec(lt, dp, dm, x, st, k), rtol=1e-8,
+                               atol=1e-10)
+    np.testing.assert_allclose(e.x_partial_Q_y(lt, x, p, st), O.x_partial_Q_y(lt, x, p, st), rtol=1e-8, atol=1e-8)
+    a, b = e.x_partial_D_y(dp, dm, st, x, p)
+    a2, b2 = O.x_partial_D_y(dm, dp, st, x, p)
+    np.testing.assert_allclose(a, a2, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(b, b2, rtol=1e-8, atol=1e-8)
+
+
+def test_synthetic_cohort_against_oracle():
+    """BASELINE config-2 shaped rows (n = k = 12 ... scaled to n = 8 so the oracle finishes in seconds)."""
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import synthetic
+    import metmhn_amd.regularized_optimization as ro
+    n = 8
+    lt, dp, dm = synthetic.random_params(n)
+    dat = np.vstack((synthetic.full_k_cohort(n, 6), synthetic.mixed_cohort(n, 30, seed=3)))
+    s, gth, gdp, gdm = ro.score_and_grad(lt, dp, dm, dat, 0.5)
+    s2, g2, a2, b2 = O.score_and_grad(lt, dp, dm, dat, 0.5)
+    np.testing.assert_allclose(s, s2, rtol=RTOL)
+    np.testing.assert_allclose(gth, g2, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(gdp, a2, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(gdm, b2, rtol=RTOL, atol=1e-9)
+
+
+def test_small_batches_match_one_batch(engines):
+    """A tiny workspace limit forces many batches: same result."""
+    from metmhn_amd import Engine, synthetic
+    n = 8
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.mixed_cohort(n, 60, seed=5)
+    e1 = engines(n)
+    e1.set_cohort(dat)
+    a = e1.cohort_sums(lt, dp, dm)
+    e2 = Engine(n, workspace_bytes=1 << 20)
+    e2.set_cohort(dat)
+    b = e2.cohort_sums(lt, dp, dm)
+    e2.close()
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+
+
+def test_empty_and_error_paths(engines):
+    from metmhn_amd import Engine
+    e = engines(3)
+    with pytest.raises(ValueError):
+        e.set_cohort(np.zeros((2, 5), dtype=np.int8))
+    with pytest.raises(RuntimeError):
+        e.set_cohort(np.array([[0, 0, 0, 0, 0, 0, 0, 0, 7]], dtype=np.int8))       # bad type
+    with pytest.raises(RuntimeError):
+        e.set_cohort(np.array([[1, 1, 0, 0, 0, 0, 0, 1, 3]], dtype=np.int8))       # paired row without seeding
+    with pytest.raises(RuntimeError):
+        Engine(3, device=99)
