@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Benchmark of the metMHN hot path on MI355X.
+
+One "step" = one full-cohort evaluation of regularized_optimization.score_and_grad_reg
+(value + full gradient, perc_met = 0.5, symmetric_penal, lambda = 1e-3): parameter upload,
+every kernel of the likelihood/gradient pipeline, the RCCL all-reduce of the partial sums
+when N > 1, the download and the host-side penalty.  Workload at every N: BASELINE.json
+configs[2] per GPU - synthetic "full-k" cohort, n = 20 events, 5 000 paired patients per
+GPU (k = 20 -> 2^20-state vectors, 8 MiB fp64 each), weak scaling; the cohort is resident
+in HBM (uploaded and laid out before the timed region).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` counts 5 000-patient cohort evaluations per second
+over all ranks (N GPUs evaluate an N x 5 000 patient cohort per step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=20, help="events (k = n active bits per patient)")
+    ap.add_argument("--patients", type=int, default=5000, help="patients per GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="patients timed on the CPU baseline (-1: 1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kronvec-batch", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(n, params, dat, sample):
+    """C restatement of the reference pass structure (oracle/metmhn_ref.c) on the host cores."""
+    from oracle import cref                      # checker / baseline only
+    lt, dp, dm = params
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    if sample < 0:
+        sample = 1
+    rows = dat[:sample]
+    cref.load()
+    t0 = time.perf_counter()
+    # few large patients: one after the other, every pass over the 2^k vector split across the cores
+    cref.patients(lt, dp, dm, rows, with_grad=True, threads=cores, patient_parallel=False)
+    dt = time.perf_counter() - t0
+    return dict(value=(sample / dt) / 5000.0, unit="evals/s", cores=cores, kind="port",
+                sample=f"{sample} of the {dat.shape[0]} patients of the same n={n} cohort (log-lik + gradient, "
+                       f"reference pass structure, OpenMP inside each pass on {cores} threads), "
+                       f"{dt:.1f} s wall, extrapolated linearly to 5000 patients")
+
+
+def main():
+    a = parse()
+    T0 = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from metmhn_amd import synthetic, distributed as D
+    import metmhn_amd.regularized_optimization as ro
+    ro.configure(device=local, dtype=a.dtype, shard=True)
+
+    n, N = a.n, a.n + 1
+    lt, dp, dm = synthetic.random_params(n)
+    # global cohort = `world` blocks of `patients` rows; the engine of rank r keeps the LPT shard r
+    dat = np.vstack([synthetic.full_k_cohort(n, a.patients, seed=2000 + n + 7919 * r) for r in range(world)])
+    params = np.concatenate((lt.flatten(), dp, dm))
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note("building cohort layout")
+    eng = ro._engine_for(dat)                    # uploads and lays out this rank's shard (outside the timed region)
+    note("cohort resident")
+
+    def step():
+        return ro.score_and_grad_reg(params, dat, 0.5, ro.symmetric_penal, 1e-3)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+        note("warmup step done")
+    eng.reset_counters()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        val, grad = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cnt = eng.counters()
+    note(f"timed region done: {dt:.2f} s for {a.steps} steps")
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * (a.patients / 5000.0) * a.steps / dt
+        kern_ms = cnt["sweep_ms"] / max(cnt["sweep_launches"], 1)
+        achieved = cnt["sweep_alg_bytes"] / max(cnt["sweep_ms"], 1e-9) / 1e6      # GB/s
+        out = {
+            "metric": "full-cohort log-lik+grad evals/sec at n=20 events; kronvec HBM GB/s",
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"synthetic full-k cohort, n={n} events, {a.patients} paired patients per GPU, "
+                                   f"2^{n}-state vectors, {a.dtype} (BASELINE.json configs[2] per GPU)",
+                       "patients_total": world * a.patients, "perc_met": 0.5, "penalty": "symmetric_penal 1e-3",
+                       "parallelism": f"patient-shard x{world}, one all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval",
+                       "solver": os.environ.get("MMHN_SOLVER", "default"),
+                       "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "solve sweep (k_sweep / k_tsolve)", "launches": int(cnt["sweep_launches"]),
+                         "avg_launch_ms": kern_ms,
+                         "alg_bytes_per_launch": cnt["sweep_alg_bytes"] / max(cnt["sweep_launches"], 1)},
+        }
+        # metric 2: batched kronvec Q_off p on resident vectors (working set > 256 MiB Infinity Cache)
+        st = dat[0, :2 * n + 1]
+        kb = a.kronvec_batch
+        V = (2 ** int(st.sum())) * (8 if a.dtype == "f64" else 4)
+        kv = {}
+        for name, tr, jac, mult in (("kronvec", 0, 0, 2), ("kronvec_T", 1, 0, 2), ("jacobi_step", 0, 1, 4)):
+            ms = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac)
+            kv[name] = {"ms_per_launch": ms, "alg_GBps": mult * V * kb / ms / 1e6, "frac_of_peak": mult * V * kb / ms / 1e6 / HBM_PEAK_GBPS,
+                        "batch": kb, "alg_bytes_per_launch": mult * V * kb}
+        out["kronvec"] = kv
+        note("kronvec leg done")
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(n, (lt, dp, dm), dat, a.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""ctypes access to oracle/_build/libmetmhn_ref.so (C restatement; checker / CPU baseline only)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_build", "libmetmhn_ref.so")
+_f = C.POINTER(C.c_double)
+_i8 = C.POINTER(C.c_int8)
+_lib = None
+
+
+def load(build: bool = True):
+    global _lib
+    if _lib is None:
+        if build and (not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "metmhn_ref.c"))):
+            subprocess.run(["make", "-s", "-C", _HERE], check=True)
+        _lib = C.CDLL(LIB)
+        _lib.ref_patients.argtypes = [C.c_int, _f, _f, _f, _i8, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f]
+        _lib.ref_kronvec.argtypes = [C.c_int, _f, _i8, _f, _f, C.c_int, C.c_int]
+        _lib.ref_num_threads.restype = C.c_int
+    return _lib
+
+
+def num_threads() -> int:
+    return load().ref_num_threads()
+
+
+def patients(log_theta, log_d_p, log_d_m, dat, with_grad=True, threads=0, patient_parallel=True):
+    """Per-patient (lp, d_theta, d_dp, d_dm) of the rows of `dat`.
+
+    patient_parallel=True: OpenMP over patients (many small patients); False: patients one after the
+    other with every pass over the 2^k vector split across the threads (few large patients)."""
+    lib = load()
+    lt = np.ascontiguousarray(log_theta, dtype=np.float64)
+    dp = np.ascontiguousarray(log_d_p, dtype=np.float64)
+    dm = np.ascontiguousarray(log_d_m, dtype=np.float64)
+    dat = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+    n = (dat.shape[1] - 3) // 2
+    N, P = n + 1, dat.shape[0]
+    lp = np.zeros(P)
+    g, a, b = np.zeros((P, N, N)), np.zeros((P, N)), np.zeros((P, N))
+    rc = lib.ref_patients(n, lt.ctypes.data_as(_f), dp.ctypes.data_as(_f), dm.ctypes.data_as(_f),
+                          dat.ctypes.data_as(_i8), P, int(with_grad), int(threads), int(patient_parallel),
+                          lp.ctypes.data_as(_f),
+                          g.ctypes.data_as(_f), a.ctypes.data_as(_f), b.ctypes.data_as(_f))
+    if rc != 0:
+        raise RuntimeError("ref_patients failed")
+    return lp, g, a, b
+
+
+def kronvec(log_theta, p, state, diag=True, transpose=False):
+    lib = load()
+    lt = np.ascontiguousarray(log_theta, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    st = np.ascontiguousarray(np.asarray(state).astype(np.int8))
+    y = np.zeros_like(p)
+    lib.ref_kronvec((st.shape[0] - 1) // 2, lt.ctypes.data_as(_f), st.ctypes.data_as(_i8), p.ctypes.data_as(_f),
+                    y.ctypes.data_as(_f), int(diag), int(transpose))
+    return y
