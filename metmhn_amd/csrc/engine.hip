@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,10 +82,25 @@ struct Batch {
   long long vecJ = 0, vecS = 0, asize = 0;
   int maxkJ = 0, maxkS = 0;
   bool has_kind2 = false;
+  // tiles sorted by level = popcount(tile index) for the substitution solver; lof* = level offsets
+  std::vector<int2> lmapJ, lmapS;
+  std::vector<int> lofJ, lofS;
   DevArr<PatRec> d_pats;
   DevArr<Desc> d_dJ, d_dS;
-  DevArr<int2> d_mapJ, d_mapS;
+  DevArr<int2> d_mapJ, d_mapS, d_lmapJ, d_lmapS;
 };
+
+// sort a tile list by level (stable) and record the level offsets
+static void build_levels(const std::vector<int2>& map, std::vector<int2>& lmap, std::vector<int>& lof) {
+  int maxl = 0;
+  for (const int2& m : map) maxl = std::max(maxl, popc((uint32_t)m.y));
+  lof.assign(maxl + 2, 0);
+  for (const int2& m : map) lof[popc((uint32_t)m.y) + 1]++;
+  for (int l = 0; l <= maxl; ++l) lof[l + 1] += lof[l];
+  lmap.resize(map.size());
+  std::vector<int> cur(lof.begin(), lof.end() - 1);
+  for (const int2& m : map) lmap[cur[popc((uint32_t)m.y)]++] = m;
+}
 
 static inline long long a_size(const Desc& d) {
   const int kP = popc(d.maskP), kM = popc(d.maskM), kE = popc(d.pairP);
@@ -117,6 +133,10 @@ struct Engine : EngineBase {
   // workspace (sized for the largest batch)
   DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, dots, bmJ, bmS;
   DevArr<double> lp, out, sums;
+  // popcount-ordered state permutations of every tile size (k_tsolve step B)
+  DevArr<uint16_t> d_perm;
+  DevArr<int> d_lvl;
+  bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
   // counters
   mmhn_counters cnt{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -133,8 +153,31 @@ struct Engine : EngineBase {
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
     ws_limit = (size_t)(0.7 * (double)free_b);
+    {
+      std::vector<uint16_t> perm((size_t)(TB + 1) << TB, 0);
+      std::vector<int> lvl((size_t)(TB + 1) * (TB + 2), 0);
+      for (int t = 0; t <= TB; ++t) {
+        int pos = 0;
+        for (int l = 0; l <= t; ++l) {
+          lvl[(size_t)t * (TB + 2) + l] = pos;
+          for (uint32_t x = 0; x < (1u << t); ++x)
+            if (popc(x) == l) perm[((size_t)t << TB) + pos++] = (uint16_t)x;
+        }
+        lvl[(size_t)t * (TB + 2) + t + 1] = pos;
+      }
+      d_perm.alloc(perm.size());
+      d_lvl.alloc(lvl.size());
+      HIPCHECK(hipMemcpy(d_perm.p, perm.data(), perm.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(d_lvl.p, lvl.data(), lvl.size() * sizeof(int), hipMemcpyHostToDevice));
+      const char* sv = std::getenv("MMHN_SOLVER");
+      use_jacobi = sv && std::string(sv) == "jacobi";
+    }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, true>),
@@ -237,13 +280,60 @@ struct Engine : EngineBase {
   void zero(T* p, long long count) {
     if (count > 0) HIPCHECK(hipMemsetAsync(p, 0, (size_t)count * sizeof(T), stream));
   }
-  // (D - Q)^-1 rhs on every problem of a list: k+1 in-place fused Jacobi sweeps from zero
-  void solve(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, long long vec, T* y, const T* lidg,
-             const T* rhs, int rhs_mode, const T* scal) {
-    if (ntiles == 0) return;
-    zero(y, vec);
-    const double bytes = 4.0 * (double)vec * sizeof(T);   // read y, lidg, rhs; write y (B_js)
-    for (int s = 0; s <= maxk; ++s) launch_sweep(tr, descs, map, ntiles, maxk, y, y, lidg, rhs, rhs_mode, scal, bytes);
+  // timed launch helper shared by the two solvers
+  template <typename F>
+  void timed(double alg_bytes, F&& launch) {
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t a, b;
+      HIPCHECK(hipEventCreate(&a));
+      HIPCHECK(hipEventCreate(&b));
+      ev_pool.push_back({a, b});
+    }
+    hipEvent_t e0 = ev_pool[ev_used].first, e1 = ev_pool[ev_used].second;
+    ++ev_used;
+    ev_bytes.push_back(alg_bytes);
+    HIPCHECK(hipEventRecord(e0, stream));
+    launch();
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(e1, stream));
+  }
+
+  // one list of problems with its tile maps
+  struct PList {
+    const Desc* d; const int2* map; int ntiles; int maxk; long long vec;
+    const int2* lmap; const std::vector<int>* lof;
+  };
+
+  // (D - Q)^-1 rhs (tr: transposed) on every problem of a list.
+  //   default: tile-level substitution (k_tsolve), one launch per level of tile-index popcount;
+  //   MMHN_SOLVER=jacobi: k+1 in-place fused Jacobi sweeps from zero (the reference's iteration).
+  void solve(bool tr, const PList& L, T* y, const T* lidg, const T* rhs, int rhs_mode, const T* scal) {
+    if (L.ntiles == 0) return;
+    if (use_jacobi) {
+      zero(y, L.vec);
+      const double bytes = 4.0 * (double)L.vec * sizeof(T);   // read y, lidg, rhs; write y (B_js)
+      for (int s = 0; s <= L.maxk; ++s)
+        launch_sweep(tr, L.d, L.map, L.ntiles, L.maxk, y, y, lidg, rhs, rhs_mode, scal, bytes);
+      return;
+    }
+    const int nlev = (int)L.lof->size() - 1;
+    const size_t lds = sweep_lds(L.maxk);
+    const int mk = std::max(L.maxk, 1);
+    for (int s = 0; s < nlev; ++s) {
+      const int lev = tr ? nlev - 1 - s : s;
+      const int beg = (*L.lof)[lev], cntl = (*L.lof)[lev + 1] - beg;
+      if (cntl == 0) continue;
+      // compulsory traffic of a tile: read lidg (+ dense rhs), write y
+      const double per_tile = (double)(rhs_mode == 0 ? 3 : 2) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);
+      timed(per_tile * cntl, [&]() {
+        if (tr)
+          hipLaunchKernelGGL((k_tsolve<T, true>), dim3(cntl), dim3(BLOCK), lds, stream, L.d, L.lmap + beg, d_par.p, y,
+                             lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk);
+        else
+          hipLaunchKernelGGL((k_tsolve<T, false>), dim3(cntl), dim3(BLOCK), lds, stream, L.d, L.lmap + beg, d_par.p,
+                             y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk);
+      });
+    }
   }
 
   // ---------------------------------------------------------------- cohort
@@ -354,7 +444,10 @@ struct Engine : EngineBase {
         dev.alloc(host.size());
         HIPCHECK(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
       };
+      build_levels(b.mapJ, b.lmapJ, b.lofJ);
+      build_levels(b.mapS, b.lmapS, b.lofS);
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
+      up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
@@ -386,9 +479,11 @@ struct Engine : EngineBase {
     for (Batch& b : batches) {
       const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
       const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
+      const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ};
+      const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS};
       // 1-2 joint forward
       launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
-      solve(false, b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, pi.p, lidgJ.p, nullptr, 2, nullptr);
+      solve(false, LJ, pi.p, lidgJ.p, nullptr, 2, nullptr);
       // 3 marginal right-hand sides
       zero(rhsS.p, b.vecS);
       if (nJ) {
@@ -399,12 +494,12 @@ struct Engine : EngineBase {
       fill_e0(b);
       // 4 single-tumour spaces
       launch_diag(b.d_dS.p, b.d_mapS.p, tS, nullptr, lidgS.p, nullptr, KD_LIDG);
-      solve(false, b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
+      solve(false, LS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
       hipLaunchKernelGGL((k_seeds<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
                          d_par.p, pS.p, seedS.p, lp.p);
       HIPCHECK(hipGetLastError());
       if (grad) {
-        solve(true, b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, qS.p, lidgS.p, nullptr, 1, seedS.p);
+        solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
         launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S);
         if (b.has_kind2) {
           zero(bmS.p, (long long)nS * 64);
@@ -420,7 +515,7 @@ struct Engine : EngineBase {
                                b.d_dS.p, d_par.p, qS.p, rhsS.p, rhsJ.p, dots.p, part);
             HIPCHECK(hipGetLastError());
           }
-          solve(true, b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
+          solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
           // 6 joint gradient
           hipLaunchKernelGGL((k_class_marg<T>), dim3(nJ, 2, 4), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p,
                              Abuf.p);
@@ -481,9 +576,11 @@ struct Engine : EngineBase {
   struct Mini {
     Desc d;
     DevArr<Desc> dd;
-    DevArr<int2> map;
+    DevArr<int2> map, lmap;
+    std::vector<int> lof;
     int ntiles = 0;
     DevArr<T> a, b, c, e;
+    PList plist(long long vec) const { return PList{dd.p, map.p, ntiles, d.k, vec, lmap.p, &lof}; }
   };
   void mini_setup(Mini& m, const Desc& d) {
     m.d = d;
@@ -492,6 +589,10 @@ struct Engine : EngineBase {
     std::vector<int2> mp;
     add_tiles(mp, 0, d.k);
     m.ntiles = (int)mp.size();
+    std::vector<int2> lm;
+    build_levels(mp, lm, m.lof);
+    m.lmap.alloc(lm.size());
+    HIPCHECK(hipMemcpyAsync(m.lmap.p, lm.data(), lm.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
     m.dd.alloc(1); m.map.alloc(mp.size());
     HIPCHECK(hipMemcpyAsync(m.dd.p, &m.d, sizeof(Desc), hipMemcpyHostToDevice, stream));
     HIPCHECK(hipMemcpyAsync(m.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -535,7 +636,7 @@ struct Engine : EngineBase {
     if (dvec) up(m.e, dvec, V);
     m.b.alloc(V); m.c.alloc(V);
     launch_diag(m.dd.p, m.map.p, m.ntiles, nullptr, m.c.p, m.e.p, KD_LIDG);
-    solve(tr, m.dd.p, m.map.p, m.ntiles, d.k, (long long)V, m.b.p, m.c.p, m.a.p, 0, nullptr);
+    solve(tr, m.plist((long long)V), m.b.p, m.c.p, m.a.p, 0, nullptr);
     down(y, m.b.p, V);
   }
   void api_xQy_joint(const Desc& d0, const double* x, const double* y, double* G) {

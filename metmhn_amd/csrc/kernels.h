@@ -137,6 +137,158 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
 }
 
 // ------------------------------------------------------------------------------------
+// k_tsolve: one tile of the triangular solve  (D - Q) y = rhs   (TR: transposed system).
+//
+// (D - Q) is lower triangular in index order: every transition sets bits, so y[x] only needs
+// y on subsets of x (supersets for the transpose).  Instead of the reference's k+1 Jacobi
+// sweeps (likelihood.py:253-261) each state is computed exactly once:
+//   * tiles are scheduled by levels = popcount of the tile index H (host launches level after
+//     level, ascending; descending for TR), so every neighbour tile H ^ bit is final;
+//   * step A streams the out-of-tile neighbours (coalesced global reads) into an accumulator,
+//   * step B solves the 2^t states of the tile in LDS in popcount order (perm = states sorted
+//     by popcount, one barrier per level): z = acc + sum rate * y[x ^ move], y = lidg * z,
+//   * step C writes the tile back.
+// Same result as the Jacobi iteration up to rounding (Q_off is nilpotent), 1/(k+1) of the
+// arithmetic and ~1/10 of the HBM traffic.
+// ------------------------------------------------------------------------------------
+template <typename T, bool TR>
+__global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs,
+                                                  const int2* __restrict__ lmap,
+                                                  const Params<T>* __restrict__ par, T* y,
+                                                  const T* __restrict__ lidg,
+                                                  const T* __restrict__ rhs, int rhs_mode,
+                                                  const T* __restrict__ scal,
+                                                  const uint16_t* __restrict__ perm,
+                                                  const int* __restrict__ lvl, int maxk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Desc& d = *reinterpret_cast<Desc*>(smem);
+  T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
+  T* Ltab = yt + (1 << TB);
+  T* Utab = Ltab + maxk * 64;
+  const int tid = threadIdx.x;
+  const int prob = lmap[blockIdx.x].x;
+  const uint32_t H = (uint32_t)lmap[blockIdx.x].y;
+  load_desc(&d, descs + prob);
+  __syncthreads();
+  const int k = d.k;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t, tmask = nelem - 1;
+  const long long base = d.off;
+  const int R = t > 6 ? 1 << (t - 6) : 1;
+  const Params<T>& P = par[d.pset];
+  const int nl = k < 6 ? k : 6;
+  for (int e = tid; e < k * 64; e += BLOCK) {
+    const int b = e >> 6, l = e & 63;
+    const int row = d.ev[b];
+    const int c = d.cls[b];
+    const int pc = c == CS ? CP : c;
+    T v = 1;
+    for (int bb = 0; bb < nl; ++bb)
+      if (bb != b && ((l >> bb) & 1) && d.cls[bb] == pc) v *= P.th[row][d.ev[bb]];
+    Ltab[e] = v;
+    if (l < R) {
+      T u = (c == CM) ? P.baseM[row] : P.baseP[row];
+      for (int bb = 6; bb < t; ++bb)
+        if (bb != b && ((l >> (bb - 6)) & 1) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
+      for (int bb = t; bb < k; ++bb)
+        if (bb != b && ((H >> (bb - t)) & 1u) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
+      Utab[e] = u;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool joint = d.mode == JOINT;
+  const uint32_t last = (1u << k) - 1u;
+  const uint32_t xhi = H << t;
+  constexpr int NJ = (1 << TB) / BLOCK;      // rows per thread
+
+  // ---- step A: right-hand side + transitions that cross the tile boundary
+  T acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t xl = ((uint32_t)(wave + WAVES * j) << 6) | (uint32_t)lane;
+    T rv = 0;
+    if (xl < nelem) {
+      const uint32_t x = xhi | xl;
+      if (rhs_mode == 0) rv = rhs[base + x];
+      else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
+      else rv = (x == 0) ? T(1) : T(0);
+    }
+    acc[j] = rv;
+  }
+  for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
+    const int c = d.cls[b];
+    const bool is_seed = joint && c == CS;
+    const bool is_pair = joint && ((d.pairP >> b) & 1u);
+    // candidate moves of bit b: single bit (async / seeding) and, for a paired P bit, both bits
+    for (int kind = 0; kind < 2; ++kind) {
+      if (kind == 1 && !is_pair) continue;
+      const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
+      const uint32_t mh = mv >> t, ml = mv & tmask;
+      if (mh == 0) continue;                                   // stays inside the tile: step B
+      if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;       // tile-uniform part of the condition
+      const T Lb = Ltab[b * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave + WAVES * j;
+        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+        if (xl >= nelem) continue;
+        if (TR ? (xl & ml) != 0 : (xl & ml) != ml) continue;
+        const uint32_t x = xhi | xl;
+        const bool ss = seed_set(d, x);
+        bool cond;
+        if (kind == 1) cond = !ss && eq_noseed(d, x);
+        else if (is_seed) cond = eq_noseed(d, x);
+        else cond = ss;
+        if (cond) acc[j] += Lb * Utab[b * 64 + r] * y[base + (x ^ mv)];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t xl = ((uint32_t)(wave + WAVES * j) << 6) | (uint32_t)lane;
+    if (xl < nelem) yt[xl] = acc[j];
+  }
+  __syncthreads();
+
+  // ---- step B: popcount-ordered substitution inside the tile
+  const uint16_t* pm = perm + (size_t)t * (1 << TB);
+  const int* lv = lvl + t * (TB + 2);
+  for (int s = 0; s <= t; ++s) {
+    const int level = TR ? t - s : s;
+    const int beg = lv[level], end = lv[level + 1];
+    for (int i = beg + tid; i < end; i += BLOCK) {
+      const uint32_t xl = pm[i];
+      const uint32_t x = xhi | xl;
+      const bool ss = seed_set(d, x);
+      const bool e0x = eq_noseed(d, x);
+      T z = yt[xl];
+      uint32_t todo = TR ? (~xl & tmask) : xl;
+      while (todo) {
+        const int b = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const int c = d.cls[b];
+        uint32_t mv = 1u << b;
+        bool cond;
+        if (joint && c == CS) cond = e0x;
+        else if (ss) cond = true;
+        else if ((d.pairP >> b) & 1u) {
+          mv = 3u << b;
+          cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
+        } else cond = false;
+        if (cond) z += Ltab[b * 64 + (xl & 63u)] * Utab[b * 64 + (xl >> 6)] * yt[xl ^ mv];
+      }
+      yt[xl] = lidg[base + x] * z;
+    }
+    __syncthreads();
+  }
+
+  // ---- step C
+  for (uint32_t e = tid; e < nelem; e += BLOCK) y[base + xhi + e] = yt[e];
+}
+
+// ------------------------------------------------------------------------------------
 // k_diag: diagonal quantities of one tile.
 //   KD_DQ    out = diag(Q)                           (kron_diag, kronvec.py:964-999)
 //   KD_LIDG  out = 1 / (Dobs - diag(Q))              (likelihood.py:249-250, vanilla.py:294)

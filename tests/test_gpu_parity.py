@@ -202,3 +202,22 @@ def test_empty_and_error_paths(engines):
         e.set_cohort(np.array([[1, 1, 0, 0, 0, 0, 0, 1, 3]], dtype=np.int8))       # paired row without seeding
     with pytest.raises(RuntimeError):
         Engine(3, device=99)
+
+
+def test_substitution_solver_matches_jacobi_iteration(monkeypatch):
+    """Default tile-level substitution vs the reference's k+1 Jacobi sweeps (MMHN_SOLVER=jacobi)."""
+    from metmhn_amd import Engine, synthetic
+    n = 9
+    lt, dp, dm = synthetic.random_params(n)
+    dat = np.vstack((synthetic.full_k_cohort(n, 8, k=9), synthetic.full_k_cohort(n, 4, k=15, seed=5),
+                     synthetic.mixed_cohort(n, 30, seed=9)))
+    e1 = Engine(n)
+    e1.set_cohort(dat)
+    a = e1.cohort_sums(lt, dp, dm)
+    e1.close()
+    monkeypatch.setenv("MMHN_SOLVER", "jacobi")
+    e2 = Engine(n)
+    e2.set_cohort(dat)
+    b = e2.cohort_sums(lt, dp, dm)
+    e2.close()
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
