@@ -38,32 +38,64 @@ def parse():
     ap.add_argument("--n", type=int, default=20, help="events (k = n active bits per patient)")
     ap.add_argument("--patients", type=int, default=5000, help="patients per GPU")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="patients timed on the CPU baseline (-1: 1)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="patients timed on the CPU baseline (-1: one per core)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kronvec-batch", type=int, default=64)
     return ap.parse_args()
 
 
-def cpu_baseline(n, params, dat, sample):
-    """C restatement of the reference pass structure (oracle/metmhn_ref.c) on the host cores."""
-    from oracle import cref                      # checker / baseline only
-    lt, dp, dm = params
+def host_cores():
+    """CPU share of this process: affinity, capped by the cgroup quota and by 16 (one GPU's share of the box)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(cores, 16))
+
+
+_CPU_SCRIPT = """
+import sys, time, json, numpy as np
+sys.path.insert(0, {root!r})
+from oracle import cref                      # checker / baseline only
+from metmhn_amd import synthetic
+n, sample, cores = {n}, {sample}, {cores}
+lt, dp, dm = synthetic.random_params(n)
+dat = synthetic.full_k_cohort(n, {patients}, seed=2000 + n)
+cref.load()
+t0 = time.perf_counter()
+cref.patients(lt, dp, dm, dat[:sample], with_grad=True, threads=cores, patient_parallel=True)
+print(json.dumps(dict(dt=time.perf_counter() - t0)))
+"""
+
+
+def cpu_baseline(n, patients, sample, budget_s=300):
+    """C restatement of the reference pass structure (oracle/metmhn_ref.c) on the host cores.
+
+    Runs in a fresh process (own OpenMP runtime, passive waits, thread count = CPU share) on a bounded
+    sample of the same cohort: one patient per core, OpenMP over patients."""
+    import subprocess
+    cores = host_cores()
     if sample < 0:
-        sample = 1
-    rows = dat[:sample]
-    cref.load()
-    t0 = time.perf_counter()
-    # few large patients: one after the other, every pass over the 2^k vector split across the cores
-    cref.patients(lt, dp, dm, rows, with_grad=True, threads=cores, patient_parallel=False)
-    dt = time.perf_counter() - t0
+        sample = cores
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0",
+               OMP_PROC_BIND="false")
+    code = _CPU_SCRIPT.format(root=ROOT, n=n, sample=sample, cores=cores, patients=patients)
+    try:
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=budget_s)
+        dt = json.loads(res.stdout.strip().splitlines()[-1])["dt"]
+    except Exception as exc:                      # report the failure instead of hanging the bench
+        return dict(value=None, unit="evals/s", cores=cores, kind="port",
+                    sample=f"CPU baseline did not finish within {budget_s} s ({type(exc).__name__})")
     return dict(value=(sample / dt) / 5000.0, unit="evals/s", cores=cores, kind="port",
-                sample=f"{sample} of the {dat.shape[0]} patients of the same n={n} cohort (log-lik + gradient, "
-                       f"reference pass structure, OpenMP inside each pass on {cores} threads), "
+                sample=f"{sample} of the {patients} patients of the same n={n} cohort (log-lik + gradient, "
+                       f"reference pass structure, OpenMP over patients on {cores} threads), "
                        f"{dt:.1f} s wall, extrapolated linearly to 5000 patients")
 
 
@@ -157,7 +189,7 @@ def main():
         out["kronvec"] = kv
         note("kronvec leg done")
         if world == 1 and not a.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(n, (lt, dp, dm), dat, a.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(n, a.patients, a.cpu_sample)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
