@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SRC = [os.path.join(_HERE, "csrc", f) for f in ("engine.hip", "kernels.h", "desc.h")]
 _HDR = os.path.join(_ROOT, "include", "metmhn_amd.h")
-LIB_PATH = os.path.join(_HERE, "libmetmhn_amd.so")
+LIB_PATH = os.environ.get("MMHN_LIB", os.path.join(_HERE, "libmetmhn_amd.so"))   # MMHN_LIB: A/B builds
 
 f64p = C.POINTER(C.c_double)
 i8p = C.POINTER(C.c_int8)

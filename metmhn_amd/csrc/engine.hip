@@ -131,7 +131,7 @@ struct Engine : EngineBase {
   std::vector<Batch> batches;
   double n_em = 0;
   // workspace (sized for the largest batch)
-  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, dots, bmJ, bmS;
+  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS;
   DevArr<double> lp, out, sums;
   // popcount-ordered state permutations of every tile size (k_tsolve step B)
   DevArr<uint16_t> d_perm;
@@ -185,6 +185,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_diag<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_rows<T>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_class_marg<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   ~Engine() override {
@@ -269,12 +271,15 @@ struct Engine : EngineBase {
                        what, N);
     HIPCHECK(hipGetLastError());
   }
-  void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind) {
+  // dj != nullptr (joint kinds): one extra row per problem with the observation-rate gradient
+  void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind,
+                        T* dj = nullptr) {
     if (nprob == 0) return;
     const int maxhi = std::max(0, maxk - 6);
     const size_t lds = ((size_t)WAVES * 64 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
-    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (N + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream, descs,
-                       d_par.p, A, p, q, G, kind, maxhi);
+    const int rows = N + (dj ? 1 : 0);
+    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream, descs,
+                       d_par.p, A, p, q, G, kind, maxhi, dj);
     HIPCHECK(hipGetLastError());
   }
   void zero(T* p, long long count) {
@@ -454,7 +459,7 @@ struct Engine : EngineBase {
     pi.alloc(mvJ); lidgJ.alloc(mvJ); qJ.alloc(mvJ); rhsJ.alloc(mvJ);
     rhsS.alloc(mvS); pS.alloc(mvS); lidgS.alloc(mvS); qS.alloc(mvS);
     seedS.alloc(mnS); Abuf.alloc(mA);
-    GS.alloc(mnS * N * N); GJ.alloc(3 * mnJ * N * N);
+    GS.alloc(mnS * N * N); GJ.alloc(3 * mnJ * N * N); DJ.alloc(3 * mnJ * N);
     dots.alloc(2 * mp); bmJ.alloc(mnJ * 64); bmS.alloc(mnS * 64);
     lp.alloc(mp); out.alloc(mp * stride());
   }
@@ -517,23 +522,20 @@ struct Engine : EngineBase {
           }
           solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
           // 6 joint gradient
-          hipLaunchKernelGGL((k_class_marg<T>), dim3(nJ, 2, 4), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p,
-                             Abuf.p);
+          zero(Abuf.p, b.asize);
+          hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(BLOCK), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
+                             b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           const long long gjs = (long long)nJ * N * N;
           for (int kd = 0; kd < 3; ++kd)
-            launch_grad_rows(b.d_dJ.p, nJ, b.maxkJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd);
-          zero(bmJ.p, (long long)nJ * 64);
-          hipLaunchKernelGGL((k_bit_marg<T>), dim3(tJ), dim3(BLOCK), 0, stream, b.d_dJ.p, b.d_mapJ.p, d_par.p, pi.p,
-                             qJ.p, bmJ.p);
-          HIPCHECK(hipGetLastError());
+            launch_grad_rows(b.d_dJ.p, nJ, b.maxkJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, DJ.p);
         }
         // 7 assembly
       }
       hipLaunchKernelGGL((k_finalize<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p, b.d_dS.p,
-                         d_par.p, GS.p, GJ.p, (long long)nJ * N * N, dots.p, bmJ.p, bmS.p, lp.p, out.p, N,
+                         d_par.p, GS.p, GJ.p, (long long)nJ * N * N, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, out.p, N,
                          grad ? 1 : 0);
       HIPCHECK(hipGetLastError());
       hipLaunchKernelGGL(k_reduce, dim3(grad ? st : 1, 2), dim3(BLOCK), 0, stream, b.d_pats.p, npat, out.p, st,
@@ -646,7 +648,9 @@ struct Engine : EngineBase {
     up(m.b, x, V);   // q (left vector)
     m.c.alloc((size_t)a_size(m.d));
     m.e.alloc((size_t)3 * N * N);
-    hipLaunchKernelGGL((k_class_marg<T>), dim3(1, 2, 4), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
+    zero(m.c.p, a_size(m.d));
+    hipLaunchKernelGGL((k_class_marg<T>), dim3(m.ntiles), dim3(BLOCK), 2 * sizeof(T) << TB, stream, m.dd.p, m.map.p,
+                       m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());

@@ -177,6 +177,19 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
   const int R = t > 6 ? 1 << (t - 6) : 1;
   const Params<T>& P = par[d.pset];
   const int nl = k < 6 ? k : 6;
+  const uint32_t xhi = H << t;
+  constexpr int NJ = (1 << TB) / BLOCK;      // states per thread
+  // step-B operands of this thread's states (perm order), fetched now so that their latency
+  // hides behind the table build and step A: state index and 1/(D - diag Q)
+  const uint16_t* pm = perm + (size_t)t * (1 << TB);
+  uint32_t px[NJ];
+  T lid[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t idx = (uint32_t)tid + BLOCK * j;
+    px[j] = idx < nelem ? pm[idx] : 0u;
+    lid[j] = idx < nelem ? lidg[base + xhi + px[j]] : T(0);
+  }
   for (int e = tid; e < k * 64; e += BLOCK) {
     const int b = e >> 6, l = e & 63;
     const int row = d.ev[b];
@@ -200,8 +213,6 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
   const int wave = tid >> 6, lane = tid & 63;
   const bool joint = d.mode == JOINT;
   const uint32_t last = (1u << k) - 1u;
-  const uint32_t xhi = H << t;
-  constexpr int NJ = (1 << TB) / BLOCK;      // rows per thread
 
   // ---- step A: right-hand side + transitions that cross the tile boundary
   T acc[NJ];
@@ -253,13 +264,17 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
   __syncthreads();
 
   // ---- step B: popcount-ordered substitution inside the tile
-  const uint16_t* pm = perm + (size_t)t * (1 << TB);
   const int* lv = lvl + t * (TB + 2);
+  const uint32_t pairP = d.pairP;
+  const int seedb = joint ? d.seedbit : -1;
   for (int s = 0; s <= t; ++s) {
     const int level = TR ? t - s : s;
     const int beg = lv[level], end = lv[level + 1];
-    for (int i = beg + tid; i < end; i += BLOCK) {
-      const uint32_t xl = pm[i];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int idx = tid + BLOCK * j;
+      if (idx < beg || idx >= end) continue;
+      const uint32_t xl = px[j];
       const uint32_t x = xhi | xl;
       const bool ss = seed_set(d, x);
       const bool e0x = eq_noseed(d, x);
@@ -268,18 +283,17 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
       while (todo) {
         const int b = __ffs(todo) - 1;
         todo &= todo - 1;
-        const int c = d.cls[b];
         uint32_t mv = 1u << b;
         bool cond;
-        if (joint && c == CS) cond = e0x;
+        if (b == seedb) cond = e0x;
         else if (ss) cond = true;
-        else if ((d.pairP >> b) & 1u) {
+        else if ((pairP >> b) & 1u) {
           mv = 3u << b;
           cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
         } else cond = false;
         if (cond) z += Ltab[b * 64 + (xl & 63u)] * Utab[b * 64 + (xl >> 6)] * yt[xl ^ mv];
       }
-      yt[xl] = lidg[base + x] * z;
+      yt[xl] = lid[j] * z;
     }
     __syncthreads();
   }
@@ -537,56 +551,92 @@ __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* _
 //   slot 1 + l  V_l[S] =   sum_T p[S|T] q[S|T|bit_l]      (bit_l not in S, else 0)
 // for class c in {P, M}: S over subsets of the class' bits, T over the other class' bits,
 // seeding bit set.  Layout at A + d.aoff: class P block [(kP+1)][2^kP], class M block
-// [(kM+1)][2^kM], then the eq block of k_eq_flows.  One workgroup per (problem, class);
-// each wave owns (slot, S) items and strides T across its lanes.
+// [(kM+1)][2^kM], then the eq block of k_eq_flows.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ long long class_block_size(int kc) { return (long long)(kc + 1) << kc; }
 
+// Tile formulation: one workgroup stages a tile of p and q in LDS and runs one phase per class.
+// In the phase of class c a thread owns one setting `own` of the tile's class-c bits and walks the
+// settings of the tile's other bits, so the sum over T is a register accumulation; partial sums of
+// tiles that differ only in the other class' high bits meet through atomics (A is zeroed per call).
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_class_marg(const Desc* __restrict__ dJ,
+                                                      const int2* __restrict__ map,
                                                       const T* __restrict__ p,
                                                       const T* __restrict__ q, T* A) {
-  const Desc& d = dJ[blockIdx.x];
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* pt = reinterpret_cast<T*>(smem);
+  T* qt = pt + (1 << TB);
+  __shared__ T part[BLOCK];
+  const Desc& d = dJ[map[blockIdx.x].x];
+  const uint32_t H = (uint32_t)map[blockIdx.x].y;
   if (d.seedbit < 0) return;
-  const int c = blockIdx.y;
-  const uint32_t cm = c == 0 ? d.maskP : d.maskM;
-  const uint32_t om = c == 0 ? d.maskM : d.maskP;
-  const int kc = __popc(cm), ko = __popc(om);
-  const uint32_t sb = 1u << d.seedbit;
-  T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(__popc(d.maskP)));
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.z * BLOCK + threadIdx.x) >> 6;
-  const int nwave = gridDim.z * WAVES;
-  // lane part of T: the 6 lowest bits of the other class; remaining bits iterate uniformly
-  uint32_t lowm = 0, mm = om;
-  for (int i = 0; i < 6 && mm; ++i) { const uint32_t low = mm & (0u - mm); lowm |= low; mm ^= low; }
-  const uint32_t upm = om & ~lowm;
-  const int klow = __popc(lowm);
-  const bool lane_on = lane < (1 << klow);
-  const uint32_t tl = pdep32((uint32_t)lane, lowm);
-  const long long items = (long long)(kc + 1) << kc;
-  for (long long it = wave; it < items; it += nwave) {
-    const int slot = (int)(it >> kc);
-    const uint32_t s = (uint32_t)(it & ((1ll << kc) - 1));
-    const uint32_t S = pdep32(s, cm);
-    uint32_t bitl = 0;
-    bool valid = true;
-    if (slot > 0) {
-      bitl = pdep32(1u << (slot - 1), cm);
-      valid = (S & bitl) == 0;
-    }
-    T acc = 0;
-    if (valid && lane_on) {
-      uint32_t tu = 0;
-      const uint32_t cnt = 1u << (ko - klow);
-      for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t x = S | tu | tl | sb;
-        acc += p[d.off + x] * q[d.off + (x | bitl)];
-        tu = ((tu | ~upm) + 1u) & upm;
+  const int k = d.k;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t, tmask = nelem - 1;
+  const uint32_t xhi = H << t;
+  const uint32_t sbm = 1u << d.seedbit;
+  if (d.seedbit >= t && !(xhi & sbm)) return;             // tile lies in the seed = 0 half
+  const uint32_t sfix = d.seedbit < t ? sbm : 0u;         // seeding bit inside the tile: fixed to 1
+  const int tid = threadIdx.x;
+  for (uint32_t e = tid; e < nelem; e += BLOCK) { pt[e] = p[d.off + xhi + e]; qt[e] = q[d.off + xhi + e]; }
+  __syncthreads();
+  const int kP = __popc(d.maskP);
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t cmask = c == 0 ? d.maskP : d.maskM;
+    const uint32_t cm = cmask & tmask;                    // class bits inside the tile
+    const uint32_t fm = tmask & ~cm & ~sfix;              // bits summed over
+    const int nc = __popc(cm), nf = __popc(fm), kc = __popc(cmask);
+    T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(kP));
+    // compact index of the tile's high class bits (pext keeps bit order: low bits first)
+    uint32_t shi = 0;
+    { uint32_t m = cmask & ~tmask; int pos = 0; while (m) { const uint32_t low = m & (0u - m); if (xhi & low) shi |= 1u << pos; ++pos; m ^= low; } }
+    const uint32_t no = 1u << nc;
+    const int gb = no >= BLOCK ? 0 : (8 - nc < nf ? 8 - nc : nf);   // log2 of thread groups per `own`
+    const uint32_t G = 1u << gb;
+    uint32_t glow = 0, mm = fm;
+    for (int i = 0; i < gb; ++i) { const uint32_t low = mm & (0u - mm); glow |= low; mm ^= low; }
+    const uint32_t fup = fm & ~glow;
+    const uint32_t cnt = 1u << (nf - gb);
+    const uint32_t items = no * G;
+    for (int slot = 0; slot <= kc; ++slot) {
+      uint32_t bitl = 0;
+      if (slot > 0) {
+        bitl = pdep32(1u << (slot - 1), cmask);
+        if (bitl & ~tmask & xhi) continue;                // bit already set in every state of the tile
+      }
+      const bool hib = (bitl & ~tmask) != 0;              // neighbour lives in another tile
+      for (uint32_t w0 = 0; w0 < items; w0 += BLOCK) {
+        const uint32_t w = w0 + tid;
+        T acc = 0;
+        uint32_t own = 0;
+        const bool on = w < items;
+        if (on) {
+          own = w & (no - 1);
+          const uint32_t g = w >> nc;
+          const uint32_t xo = pdep32(own, cm) | pdep32(g, glow) | sfix;
+          if (!(xo & bitl)) {
+            uint32_t fu = 0;
+            for (uint32_t i = 0; i < cnt; ++i) {
+              const uint32_t xl = xo | fu;
+              const T qv = hib ? q[d.off + (xhi | bitl | xl)] : qt[xl | bitl];
+              acc += pt[xl] * qv;
+              fu = ((fu | ~fup) + 1u) & fup;
+            }
+          }
+        }
+        if (G > 1) {                                       // combine the groups that share `own`
+          __syncthreads();
+          part[tid] = acc;
+          __syncthreads();
+          if (on && (w >> nc) == 0) { for (uint32_t g = 1; g < G; ++g) acc += part[(g << nc) | own]; }
+        }
+        if (on && (G == 1 || (w >> nc) == 0) && acc != T(0)) {
+          const long long S = ((long long)shi << nc) | own;
+          atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -acc : acc);
+        }
       }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) out[((long long)slot << kc) + s] = slot == 0 ? -acc : acc;
   }
 }
 
@@ -647,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      const T* __restrict__ A,
                                                      const T* __restrict__ p,
                                                      const T* __restrict__ q, T* G, int kind,
-                                                     int maxhi) {
+                                                     int maxhi, T* DJ) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][64]
   T* rowbuf = Tlo + WAVES * 64;                 // [WAVES][32]
@@ -668,17 +718,24 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
     while (m) { const int b = __ffs(m) - 1; lev[l] = d.ev[b]; ++l; m &= m - 1; }
   }
   __syncthreads();
-  if (i >= N) return;
-  T* row = G + ((long long)blockIdx.x * N + i) * N;
+  // row N (joint kinds only): observation-rate gradient from the same marginals,
+  //   sum_S D(S) * (sum p q)[S] [l in S]  with D(S) = d0 * prod_{l in S} dvec[ev(l)]
+  //   (x_partial_D_y, likelihood.py:204-228: GK_P -> d_dp on the seed = 1 half, GK_M -> d_dm,
+  //    GK_E -> d_dp on the seed = 0 states, where D_m = 0)
+  const bool drow = i == N;
+  if (i > N || (drow && (kind == GK_S || DJ == nullptr))) return;
+  T* row = drow ? DJ + ((long long)kind * gridDim.x + blockIdx.x) * N : G + ((long long)blockIdx.x * N + i) * N;
   T* rb = rowbuf + w * 32;
   if (lane < 32) rb[lane] = 0;
+  const T* fvec = drow ? (kind == GK_M ? P.dm : P.dp) : P.th[i < N ? i : 0];
 
   bool rowvalid = true;
-  T base = kind == GK_M ? P.baseM[i] : P.baseP[i];
-  if ((kind == GK_P || kind == GK_M) && (i >= n || d.seedbit < 0)) rowvalid = false;
+  T base = drow ? (kind == GK_P ? -P.dp[n] : kind == GK_M ? -P.dm[n] : T(-1)) : (kind == GK_M ? P.baseM[i] : P.baseP[i]);
+  if ((kind == GK_P || kind == GK_M) && ((!drow && i >= n) || d.seedbit < 0)) rowvalid = false;
   if (kind == GK_E && d.mode != JOINT) rowvalid = false;
   int slot = -1;                                // local slot of event i; kc = extra always-free slot
-  if (kind == GK_E && i == n) slot = kc;
+  if (drow) slot = -1;
+  else if (kind == GK_E && i == n) slot = kc;
   else for (int l = 0; l < kc; ++l) if (lev[l] == i) slot = l;
 
   if (rowvalid) {
@@ -686,7 +743,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
     const int nhi = kc - klo;
     {
       T v = 1;
-      for (int l = 0; l < klo; ++l) if ((lane >> l) & 1) v *= P.th[i][lev[l]];
+      for (int l = 0; l < klo; ++l) if ((lane >> l) & 1) v *= fvec[lev[l]];
       Tlo[w * 64 + lane] = v;
     }
     T* ha = hiacc + (long long)w * maxhi * 64;
@@ -704,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       const long long S = S0 + lane;
       const uint32_t s = (uint32_t)S;
       T urate = base;                            // wave-uniform part of the rate
-      for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= P.th[i][lev[l]];
+      for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
       T f = 0;
       const bool blocked = slot >= 0 && slot < kc && ((s >> slot) & 1u);
       if (S < nS && !blocked) {
@@ -723,7 +780,10 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
     }
     const T total = wave_sum(tot);
-    if (lane == 0) { rb[i] = total; if (kind == GK_M) rb[n] = total; }
+    if (lane == 0) {
+      if (drow) { if (kind != GK_E) rb[n] = total; }
+      else { rb[i] = total; if (kind == GK_M) rb[n] = total; }
+    }
     for (int l = 0; l < kc; ++l) {
       const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
       const T m = wave_sum(v);
@@ -822,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(const PatRec* __restrict__ p
                                                     const T* __restrict__ GS,
                                                     const T* __restrict__ GJ, long long gj_stride,
                                                     const T* __restrict__ dots,
-                                                    const T* __restrict__ bmJ,
+                                                    const T* __restrict__ DJ, long long dj_stride,
                                                     const T* __restrict__ bmS,
                                                     const double* __restrict__ lp, double* out,
                                                     int N, int with_grad) {
@@ -882,12 +942,9 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(const PatRec* __restrict__ p
       }
     }
     if (pr.kind == 3) {                            // minus x_partial_D_y(q_J, pi), likelihood.py:536,694-695
-      const Desc& dj = dJ[pr.j];
-      const T* bm = bmJ + (long long)pr.j * 64;
-      const int bp = i == n ? dj.seedbit : dj.bitP[i];
-      const int bq = i == n ? dj.seedbit : dj.bitM[i];
-      if (bp >= 0) gp -= (double)bm[bp];
-      if (bq >= 0) gm -= (double)bm[32 + bq];
+      const long long o = (long long)pr.j * N + i;
+      gp -= (double)DJ[GK_P * dj_stride + o] + (double)DJ[GK_E * dj_stride + o];
+      gm -= (double)DJ[GK_M * dj_stride + o];
     }
     o[1 + N * N + i] = gp;
     o[1 + N * N + N + i] = gm;

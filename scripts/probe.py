@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from metmhn_amd import Engine, synthetic
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 64
