@@ -40,6 +40,7 @@ struct Desc {
   int obs;             // Obs
   long long off;       // element offset of this problem's state vectors in the batch buffers
   long long aoff;      // element offset of its gradient work arrays
+  long long toff;      // element offset of its per-evaluation tables (k_prep)
   int8_t ev[32];       // event of bit b
   int8_t cls[32];      // Cls of bit b
   int8_t bitP[32];     // event -> class-P bit or -1

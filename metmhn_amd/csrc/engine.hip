@@ -79,7 +79,8 @@ struct Batch {
   std::vector<PatRec> pats;
   std::vector<Desc> dJ, dS;
   std::vector<int2> mapJ, mapS;
-  long long vecJ = 0, vecS = 0, asize = 0;
+  long long vecJ = 0, vecS = 0, asize = 0, tabJ = 0, tabS = 0;
+  int id = 0;
   int maxkJ = 0, maxkS = 0;
   bool has_kind2 = false;
   // tiles sorted by level = popcount(tile index) for the substitution solver; lof* = level offsets
@@ -90,16 +91,38 @@ struct Batch {
   DevArr<int2> d_mapJ, d_mapS, d_lmapJ, d_lmapS;
 };
 
-// sort a tile list by level (stable) and record the level offsets
-static void build_levels(const std::vector<int2>& map, std::vector<int2>& lmap, std::vector<int>& lof) {
+// A seed = 0 tile of a joint space is dead when none of its states has PT == MT: with a right-hand
+// side supported on e_0 / the seed = 1 half the solution is identically zero there, so the engine
+// never launches it (the buffers are zeroed once; API calls with arbitrary vectors keep every tile).
+static bool dead_tile(const Desc& d, uint32_t H) {
+  if (d.mode != JOINT || d.seedbit < TB) return false;
+  const uint32_t xhi = H << TB, hmask = ~((1u << TB) - 1u);
+  if (xhi & (1u << d.seedbit)) return false;
+  if (xhi & d.lone & hmask) return true;
+  const uint32_t pp = d.pairP & hmask & ~(1u << 31);           // pairs whose P bit is a tile bit
+  const uint32_t pm = (pp << 1);
+  if (((xhi & pp) << 1) != (xhi & pm)) return true;
+  // pair straddling the tile boundary (P bit TB-1, M bit TB): M set needs P set - possible inside the tile
+  return false;
+}
+
+// sort a tile list by level (stable) and record the level offsets; prune drops dead tiles
+static void build_levels(const std::vector<int2>& map, const std::vector<Desc>* descs, bool prune,
+                         std::vector<int2>& lmap, std::vector<int>& lof) {
   int maxl = 0;
-  for (const int2& m : map) maxl = std::max(maxl, popc((uint32_t)m.y));
+  std::vector<int2> keep;
+  keep.reserve(map.size());
+  for (const int2& m : map) {
+    if (prune && descs && dead_tile((*descs)[m.x], (uint32_t)m.y)) continue;
+    keep.push_back(m);
+    maxl = std::max(maxl, popc((uint32_t)m.y));
+  }
   lof.assign(maxl + 2, 0);
-  for (const int2& m : map) lof[popc((uint32_t)m.y) + 1]++;
+  for (const int2& m : keep) lof[popc((uint32_t)m.y) + 1]++;
   for (int l = 0; l <= maxl; ++l) lof[l + 1] += lof[l];
-  lmap.resize(map.size());
+  lmap.resize(keep.size());
   std::vector<int> cur(lof.begin(), lof.end() - 1);
-  for (const int2& m : map) lmap[cur[popc((uint32_t)m.y)]++] = m;
+  for (const int2& m : keep) lmap[cur[popc((uint32_t)m.y)]++] = m;
 }
 
 static inline long long a_size(const Desc& d) {
@@ -131,7 +154,8 @@ struct Engine : EngineBase {
   std::vector<Batch> batches;
   double n_em = 0;
   // workspace (sized for the largest batch)
-  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS;
+  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS, tabJ, tabS;
+  int pi_owner = -1, qJ_owner = -1;   // batch whose (pruned) layout the zero-initialised buffers hold
   DevArr<double> lp, out, sums;
   // popcount-ordered state permutations of every tile size (k_tsolve step B)
   DevArr<uint16_t> d_perm;
@@ -174,10 +198,10 @@ struct Engine : EngineBase {
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, true>),
@@ -223,9 +247,14 @@ struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- launches
   size_t sweep_lds(int maxk) const { return DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)std::max(maxk, 1) * 64) * sizeof(T); }
+  void prep(const Desc* descs, int nprob, T* tab) {
+    if (nprob == 0) return;
+    hipLaunchKernelGGL((k_prep<T>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    HIPCHECK(hipGetLastError());
+  }
 
   void launch_sweep(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, const T* p, T* y,
-                    const T* lidg, const T* rhs, int rhs_mode, const T* scal, double alg_bytes) {
+                    const T* lidg, const T* rhs, int rhs_mode, const T* scal, double alg_bytes, const T* tab) {
     if (ntiles == 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = alg_bytes > 0;
@@ -245,10 +274,10 @@ struct Engine : EngineBase {
     const size_t lds = sweep_lds(maxk);
     if (tr)
       hipLaunchKernelGGL((k_sweep<T, true>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
-                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1));
+                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1), tab);
     else
       hipLaunchKernelGGL((k_sweep<T, false>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
-                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1));
+                         lidg, rhs, rhs_mode, scal, std::max(maxk, 1), tab);
     HIPCHECK(hipGetLastError());
     if (timed) HIPCHECK(hipEventRecord(e1, stream));
   }
@@ -306,7 +335,7 @@ struct Engine : EngineBase {
   // one list of problems with its tile maps
   struct PList {
     const Desc* d; const int2* map; int ntiles; int maxk; long long vec;
-    const int2* lmap; const std::vector<int>* lof;
+    const int2* lmap; const std::vector<int>* lof; const T* tab;
   };
 
   // (D - Q)^-1 rhs (tr: transposed) on every problem of a list.
@@ -318,7 +347,7 @@ struct Engine : EngineBase {
       zero(y, L.vec);
       const double bytes = 4.0 * (double)L.vec * sizeof(T);   // read y, lidg, rhs; write y (B_js)
       for (int s = 0; s <= L.maxk; ++s)
-        launch_sweep(tr, L.d, L.map, L.ntiles, L.maxk, y, y, lidg, rhs, rhs_mode, scal, bytes);
+        launch_sweep(tr, L.d, L.map, L.ntiles, L.maxk, y, y, lidg, rhs, rhs_mode, scal, bytes, L.tab);
       return;
     }
     const int nlev = (int)L.lof->size() - 1;
@@ -328,15 +357,19 @@ struct Engine : EngineBase {
       const int lev = tr ? nlev - 1 - s : s;
       const int beg = (*L.lof)[lev], cntl = (*L.lof)[lev + 1] - beg;
       if (cntl == 0) continue;
-      // compulsory traffic of a tile: read lidg (+ dense rhs), write y
-      const double per_tile = (double)(rhs_mode == 0 ? 3 : 2) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);
+      // compulsory traffic of a tile: write y (+ read dense rhs, + read the lidg vector when there is one)
+      const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);
       timed(per_tile * cntl, [&]() {
-        if (tr)
-          hipLaunchKernelGGL((k_tsolve<T, true>), dim3(cntl), dim3(BLOCK), lds, stream, L.d, L.lmap + beg, d_par.p, y,
-                             lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk);
-        else
-          hipLaunchKernelGGL((k_tsolve<T, false>), dim3(cntl), dim3(BLOCK), lds, stream, L.d, L.lmap + beg, d_par.p,
-                             y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk);
+        const dim3 g(cntl), bk(TSB);
+#define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab
+        if (lidg) {
+          if (tr) hipLaunchKernelGGL((k_tsolve<T, true, true>), g, bk, lds, stream, TS_ARGS);
+          else hipLaunchKernelGGL((k_tsolve<T, false, true>), g, bk, lds, stream, TS_ARGS);
+        } else {
+          if (tr) hipLaunchKernelGGL((k_tsolve<T, true, false>), g, bk, lds, stream, TS_ARGS);
+          else hipLaunchKernelGGL((k_tsolve<T, false, false>), g, bk, lds, stream, TS_ARGS);
+        }
+#undef TS_ARGS
       });
     }
   }
@@ -410,10 +443,10 @@ struct Engine : EngineBase {
       probe.vecJ = cur.vecJ + (hasJ ? (1ll << dj.k) : 0);
       probe.vecS = cur.vecS + (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
       probe.asize = cur.asize + (hasJ ? a_size(dj) : 0);
-      const size_t need = (size_t)(4 * probe.vecJ + 4 * probe.vecS + probe.asize) * sizeof(T);
+      const size_t need = (size_t)(4 * probe.vecJ + 4 * probe.vecS + probe.asize + cur.tabJ + cur.tabS) * sizeof(T);
       if (!cur.pats.empty() && need > ws_limit) flush();
       if (hasJ) {
-        dj.off = cur.vecJ; dj.aoff = cur.asize;
+        dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
         cur.vecJ += 1ll << dj.k; cur.asize += a_size(dj);
         pr.j = (int)cur.dJ.size();
         add_tiles(cur.mapJ, pr.j, dj.k);
@@ -421,14 +454,14 @@ struct Engine : EngineBase {
         cur.dJ.push_back(dj);
       }
       if (has0) {
-        ds0.off = cur.vecS; cur.vecS += 1ll << ds0.k;
+        ds0.off = cur.vecS; cur.vecS += 1ll << ds0.k; ds0.toff = cur.tabS; cur.tabS += table_size(ds0);
         pr.s[0] = (int)cur.dS.size();
         add_tiles(cur.mapS, pr.s[0], ds0.k);
         cur.maxkS = std::max(cur.maxkS, ds0.k);
         cur.dS.push_back(ds0);
       }
       if (has1) {
-        ds1.off = cur.vecS; cur.vecS += 1ll << ds1.k;
+        ds1.off = cur.vecS; cur.vecS += 1ll << ds1.k; ds1.toff = cur.tabS; cur.tabS += table_size(ds1);
         pr.s[1] = (int)cur.dS.size();
         add_tiles(cur.mapS, pr.s[1], ds1.k);
         cur.maxkS = std::max(cur.maxkS, ds1.k);
@@ -439,9 +472,11 @@ struct Engine : EngineBase {
     }
     flush();
     // upload the static descriptions and size the workspace
-    long long mvJ = 0, mvS = 0, mA = 0;
+    long long mvJ = 0, mvS = 0, mA = 0, mtJ = 0, mtS = 0;
+    int bid = 0;
     size_t mnJ = 0, mnS = 0, mp = 0;
     for (auto& b : batches) {
+      b.id = bid++;
       b.d_pats.alloc(b.pats.size());
       HIPCHECK(hipMemcpy(b.d_pats.p, b.pats.data(), b.pats.size() * sizeof(PatRec), hipMemcpyHostToDevice));
       auto up = [&](auto& dev, auto& host) {
@@ -449,14 +484,18 @@ struct Engine : EngineBase {
         dev.alloc(host.size());
         HIPCHECK(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
       };
-      build_levels(b.mapJ, b.lmapJ, b.lofJ);
-      build_levels(b.mapS, b.lmapS, b.lofS);
+      build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
+      build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
+      mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
-    pi.alloc(mvJ); lidgJ.alloc(mvJ); qJ.alloc(mvJ); rhsJ.alloc(mvJ);
+    pi.alloc(mvJ); qJ.alloc(mvJ); rhsJ.alloc(mvJ);
+    if (use_jacobi) lidgJ.alloc(mvJ);
+    tabJ.alloc(mtJ); tabS.alloc(mtS);
+    pi_owner = qJ_owner = -1;
     rhsS.alloc(mvS); pS.alloc(mvS); lidgS.alloc(mvS); qS.alloc(mvS);
     seedS.alloc(mnS); Abuf.alloc(mA);
     GS.alloc(mnS * N * N); GJ.alloc(3 * mnJ * N * N); DJ.alloc(3 * mnJ * N);
@@ -484,11 +523,16 @@ struct Engine : EngineBase {
     for (Batch& b : batches) {
       const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
       const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
-      const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ};
-      const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS};
+      const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};
+      const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS, tabS.p};
+      prep(b.d_dJ.p, nJ, tabJ.p);
+      prep(b.d_dS.p, nS, tabS.p);
+      // the substitution solver skips dead tiles: those parts of pi / q_J must hold zeros
+      if (!use_jacobi && pi_owner != b.id) { zero(pi.p, b.vecJ); pi_owner = b.id; }
+      if (!use_jacobi && grad && qJ_owner != b.id) { zero(qJ.p, b.vecJ); qJ_owner = b.id; }
       // 1-2 joint forward
-      launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
-      solve(false, LJ, pi.p, lidgJ.p, nullptr, 2, nullptr);
+      if (use_jacobi) launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
+      solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
       // 3 marginal right-hand sides
       zero(rhsS.p, b.vecS);
       if (nJ) {
@@ -520,7 +564,7 @@ struct Engine : EngineBase {
                                b.d_dS.p, d_par.p, qS.p, rhsS.p, rhsJ.p, dots.p, part);
             HIPCHECK(hipGetLastError());
           }
-          solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
+          solve(true, LJ, qJ.p, use_jacobi ? lidgJ.p : nullptr, rhsJ.p, 0, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);
           hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(BLOCK), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
@@ -581,23 +625,25 @@ struct Engine : EngineBase {
     DevArr<int2> map, lmap;
     std::vector<int> lof;
     int ntiles = 0;
-    DevArr<T> a, b, c, e;
-    PList plist(long long vec) const { return PList{dd.p, map.p, ntiles, d.k, vec, lmap.p, &lof}; }
+    DevArr<T> a, b, c, e, tab;
+    PList plist(long long vec) const { return PList{dd.p, map.p, ntiles, d.k, vec, lmap.p, &lof, tab.p}; }
   };
   void mini_setup(Mini& m, const Desc& d) {
     m.d = d;
-    m.d.off = 0; m.d.aoff = 0;
+    m.d.off = 0; m.d.aoff = 0; m.d.toff = 0;
     REQUIRE(d.k <= MAXK, "too many active events");
     std::vector<int2> mp;
     add_tiles(mp, 0, d.k);
     m.ntiles = (int)mp.size();
     std::vector<int2> lm;
-    build_levels(mp, lm, m.lof);
+    build_levels(mp, nullptr, false, lm, m.lof);
     m.lmap.alloc(lm.size());
     HIPCHECK(hipMemcpyAsync(m.lmap.p, lm.data(), lm.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
     m.dd.alloc(1); m.map.alloc(mp.size());
     HIPCHECK(hipMemcpyAsync(m.dd.p, &m.d, sizeof(Desc), hipMemcpyHostToDevice, stream));
     HIPCHECK(hipMemcpyAsync(m.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+    m.tab.alloc((size_t)std::max<long long>(table_size(m.d), 1));
+    prep(m.dd.p, 1, m.tab.p);
     HIPCHECK(hipStreamSynchronize(stream));
   }
   void up(DevArr<T>& dst, const double* src, size_t count) {
@@ -618,7 +664,7 @@ struct Engine : EngineBase {
     const size_t V = (size_t)1 << d.k;
     up(m.a, p, V);
     m.b.alloc(V);
-    launch_sweep(tr, m.dd.p, m.map.p, m.ntiles, d.k, m.a.p, m.b.p, nullptr, nullptr, 0, nullptr, 0);
+    launch_sweep(tr, m.dd.p, m.map.p, m.ntiles, d.k, m.a.p, m.b.p, nullptr, nullptr, 0, nullptr, 0, m.tab.p);
     if (diag) launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, KD_ADDQP);
     down(y, m.b.p, V);
   }
@@ -698,12 +744,15 @@ struct Engine : EngineBase {
     const long long V = 1ll << d0.k;
     std::vector<Desc> ds((size_t)batch, d0);
     std::vector<int2> mp;
-    for (long long i = 0; i < batch; ++i) { ds[i].off = i * V; ds[i].aoff = 0; add_tiles(mp, (int)i, d0.k); }
-    DevArr<Desc> dd; DevArr<int2> dm; DevArr<T> a, b, c, r;
+    const long long tsz = table_size(d0);
+    for (long long i = 0; i < batch; ++i) { ds[i].off = i * V; ds[i].aoff = 0; ds[i].toff = i * tsz; add_tiles(mp, (int)i, d0.k); }
+    DevArr<Desc> dd; DevArr<int2> dm; DevArr<T> a, b, c, r, tb;
     dd.alloc(ds.size()); dm.alloc(mp.size());
     HIPCHECK(hipMemcpy(dd.p, ds.data(), ds.size() * sizeof(Desc), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dm.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice));
     a.alloc((size_t)(batch * V)); b.alloc((size_t)(batch * V));
+    tb.alloc((size_t)(batch * tsz));
+    prep(dd.p, (int)batch, tb.p);
     std::vector<T> host((size_t)V);
     for (long long i = 0; i < V; ++i) host[(size_t)i] = (T)(1.0 / (double)(1 + (i % 97)));
     for (long long i = 0; i < batch; ++i)
@@ -715,7 +764,7 @@ struct Engine : EngineBase {
     }
     auto run = [&]() {
       launch_sweep(tr, dd.p, dm.p, (int)mp.size(), d0.k, a.p, b.p, jacobi ? c.p : nullptr, jacobi ? r.p : nullptr, 0,
-                   nullptr, 0);
+                   nullptr, 0, tb.p);
     };
     run(); run();
     hipEvent_t e0, e1;

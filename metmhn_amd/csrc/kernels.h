@@ -41,6 +41,126 @@ __device__ __forceinline__ bool seed_set(const Desc& d, uint32_t x) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_prep: per-problem tables, rebuilt once per evaluation (theta changes, the bit roles do not).
+// Layout at tab + d.toff (T elements):
+//   THc  [k][k]   THc[b][b'] = theta[ev b][ev b'] if bit b' acts on the event of bit b (same class;
+//                 the seeding bit listens to class P), else 1;  THc[b][b] = base rate of bit b
+//   Ltab [k][64]  product of THc[b][.] over the lane bits (0..5) set in l, b itself excluded
+//   Urow [k][64]  the same over the row bits (6..t-1)
+//   JOINT with seeding only - the diagonal of (D_p + D_m - Q) in Kronecker-sum form:
+//   dP [2^kP]  D_p(S) + total rate of the PT events that can still fire from PT-set S   (seed = 1 half)
+//   dM [2^kM]  the same for the metastasis;        diag(x) = dP[x_P] + dM[x_M]
+//   dE [2^kE]  diagonal on the seed = 0 states with PT == MT (index: subset of paired events)
+// so a tile gets 1/(D - diag Q) from two small table reads instead of a 2^k vector.
+// ------------------------------------------------------------------------------------
+__host__ __device__ inline long long rate_table_size(int k) { return (long long)k * k + 2ll * k * 64; }
+__host__ __device__ inline int popc32(uint32_t v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __popc(v);
+#else
+  return __builtin_popcount(v);
+#endif
+}
+__host__ __device__ inline long long table_size(const Desc& d) {
+  long long s = rate_table_size(d.k);
+  if (d.mode == JOINT && d.seedbit >= 0) s += (1ll << popc32(d.maskP)) + (1ll << popc32(d.maskM)) + (1ll << popc32(d.pairP));
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
+                                                const Params<T>* __restrict__ par, T* tab) {
+  __shared__ T thc[MAXN * MAXN];        // later reused as th[i][class bit l]
+  __shared__ Desc d;
+  load_desc(&d, descs + blockIdx.x);
+  __syncthreads();
+  const int k = d.k, tid = threadIdx.x;
+  const int t = k < TB ? k : TB;
+  const Params<T>& P = par[d.pset];
+  T* out = tab + d.toff;
+  for (int e = tid; e < k * k; e += BLOCK) {
+    const int b = e / k, bb = e % k;
+    const int row = d.ev[b], c = d.cls[b];
+    const int pc = c == CS ? CP : c;
+    T v;
+    if (bb == b) v = (c == CM) ? P.baseM[row] : P.baseP[row];
+    else v = d.cls[bb] == pc ? P.th[row][d.ev[bb]] : T(1);
+    thc[e] = v;
+    out[e] = v;
+  }
+  __syncthreads();
+  const int nl = k < 6 ? k : 6;
+  for (int e = tid; e < k * 64; e += BLOCK) {
+    const int b = e >> 6, l = e & 63;
+    T v = 1, u = 1;
+    for (int bb = 0; bb < nl; ++bb) if (bb != b && ((l >> bb) & 1)) v *= thc[b * k + bb];
+    for (int bb = 6; bb < t; ++bb) if (bb != b && ((l >> (bb - 6)) & 1)) u *= thc[b * k + bb];
+    out[k * k + e] = v;
+    out[k * k + k * 64 + e] = u;
+  }
+  if (d.mode != JOINT || d.seedbit < 0) return;
+  const int N = d.N, n = N - 1;
+  T* o = out + rate_table_size(k);
+  for (int c = 0; c < 3; ++c) {                 // 0: dP, 1: dM, 2: dE
+    const uint32_t cm = c == 0 ? d.maskP : c == 1 ? d.maskM : d.pairP;
+    const int kc = __popc(cm);
+    __syncthreads();
+    // th[i][l] = theta[i][event of the l-th class bit]
+    for (int e = tid; e < N * kc; e += BLOCK) {
+      const int i = e / kc, l = e % kc;
+      uint32_t m = cm;
+      for (int q = 0; q < l; ++q) m &= m - 1;
+      thc[e] = P.th[i][d.ev[__ffs(m) - 1]];
+    }
+    __syncthreads();
+    const T* dv = c == 1 ? P.dm : P.dp;
+    for (long long S = tid; S < (1ll << kc); S += BLOCK) {
+      T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
+      uint32_t m = cm;
+      for (int l = 0; l < kc; ++l) { const int b = __ffs(m) - 1; m &= m - 1; if ((S >> l) & 1) obs *= dv[d.ev[b]]; }
+      T tot = obs;
+      const int rows = c == 2 ? N : n;          // the eq block also carries the seeding rate (row n)
+      for (int i = 0; i < rows; ++i) {
+        // event i already happened in S ?
+        const int bi = c == 0 ? d.bitP[i] : c == 1 ? d.bitM[i] : ((i < n && d.bitP[i] >= 0 && ((d.pairP >> d.bitP[i]) & 1u)) ? d.bitP[i] : -1);
+        if (bi >= 0) {
+          const int l = __popc(cm & ((1u << bi) - 1u));
+          if ((S >> l) & 1) continue;
+        }
+        T r = c == 1 ? P.baseM[i] : P.baseP[i];
+        for (int l = 0; l < kc; ++l) if ((S >> l) & 1) r *= thc[i * kc + l];
+        tot += r;
+      }
+      o[S] = tot;
+    }
+    o += 1ll << kc;
+  }
+}
+
+// LDS tables of a tile: Ltab[rows*64], Utab[rows*64] with rows = max(maxk, 1).
+// `scratch` (k*k + k elements) may alias memory that is filled later.
+template <typename T>
+__device__ __forceinline__ void tile_tables(const Desc& d, const T* __restrict__ tab, uint32_t H, T* Ltab, T* Utab,
+                                            T* scratch) {
+  const int k = d.k, tid = threadIdx.x, nt = blockDim.x;
+  T* thc = scratch;
+  T* hx = thc + k * k;
+  const int t = k < TB ? k : TB;
+  const T* src = tab + d.toff;
+  for (int e = tid; e < k * k; e += nt) thc[e] = src[e];
+  for (int e = tid; e < k * 64; e += nt) { Ltab[e] = src[k * k + e]; Utab[e] = src[k * k + k * 64 + e]; }
+  __syncthreads();
+  if (tid < k) {
+    T h = thc[tid * k + tid];
+    for (int bb = t; bb < k; ++bb) if (bb != tid && ((H >> (bb - t)) & 1u)) h *= thc[tid * k + bb];
+    hx[tid] = h;
+  }
+  __syncthreads();
+  for (int e = tid; e < k * 64; e += nt) Utab[e] *= hx[e >> 6];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------
 // k_sweep: y = Q_off p  (TR: Q_off^T p), optionally fused Jacobi step
 //          y = lidg * (Q_off p + rhs)      (likelihood.py:253-255, vanilla.py:289-290)
 // rhs_mode: 0 dense vector, 1 scal[prob] * e_last, 2 e_0.  p and y may alias (in-place
@@ -52,7 +172,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
                                                  const Params<T>* __restrict__ par, const T* p, T* y,
                                                  const T* __restrict__ lidg,
                                                  const T* __restrict__ rhs, int rhs_mode,
-                                                 const T* __restrict__ scal, int maxk) {
+                                                 const T* __restrict__ scal, int maxk,
+                                                 const T* __restrict__ tab) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* tile = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -70,26 +191,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
   const int R = t > 6 ? 1 << (t - 6) : 1;
   const Params<T>& P = par[d.pset];
 
+  tile_tables(d, tab, H, Ltab, Utab, tile);
   for (uint32_t e = tid; e < nelem; e += BLOCK) tile[e] = p[base + ((long long)H << t) + e];
-  const int nl = k < 6 ? k : 6;
-  for (int e = tid; e < k * 64; e += BLOCK) {
-    const int b = e >> 6, l = e & 63;
-    const int row = d.ev[b];
-    const int c = d.cls[b];
-    const int pc = c == CS ? CP : c;
-    T v = 1;
-    for (int bb = 0; bb < nl; ++bb)
-      if (bb != b && ((l >> bb) & 1) && d.cls[bb] == pc) v *= P.th[row][d.ev[bb]];
-    Ltab[e] = v;
-    if (l < R) {
-      T u = (c == CM) ? P.baseM[row] : P.baseP[row];
-      for (int bb = 6; bb < t; ++bb)
-        if (bb != b && ((l >> (bb - 6)) & 1) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
-      for (int bb = t; bb < k; ++bb)
-        if (bb != b && ((H >> (bb - t)) & 1u) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
-      Utab[e] = u;
-    }
-  }
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -151,15 +254,31 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
 // Same result as the Jacobi iteration up to rounding (Q_off is nilpotent), 1/(k+1) of the
 // arithmetic and ~1/10 of the HBM traffic.
 // ------------------------------------------------------------------------------------
-template <typename T, bool TR>
-__global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs,
-                                                  const int2* __restrict__ lmap,
-                                                  const Params<T>* __restrict__ par, T* y,
-                                                  const T* __restrict__ lidg,
-                                                  const T* __restrict__ rhs, int rhs_mode,
-                                                  const T* __restrict__ scal,
-                                                  const uint16_t* __restrict__ perm,
-                                                  const int* __restrict__ lvl, int maxk) {
+constexpr int TSB = 1024;                    // threads per workgroup of k_tsolve
+
+__device__ __forceinline__ uint32_t pext32(uint32_t x, uint32_t mask) {
+  uint32_t out = 0, pos = 0;
+  while (mask) {
+    const uint32_t low = mask & (0u - mask);
+    if (x & low) out |= 1u << pos;
+    ++pos;
+    mask ^= low;
+  }
+  return out;
+}
+
+// LIDGV: 1/(D - diag Q) comes from the vector `lidg` (API path, single-tumour spaces);
+// otherwise from the class tables of k_prep (joint spaces with seeding: engine path).
+template <typename T, bool TR, bool LIDGV>
+__global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ descs,
+                                                const int2* __restrict__ lmap,
+                                                const Params<T>* __restrict__ par, T* y,
+                                                const T* __restrict__ lidg,
+                                                const T* __restrict__ rhs, int rhs_mode,
+                                                const T* __restrict__ scal,
+                                                const uint16_t* __restrict__ perm,
+                                                const int* __restrict__ lvl, int maxk,
+                                                const T* __restrict__ tab) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -174,51 +293,53 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
   const int t = k < TB ? k : TB;
   const uint32_t nelem = 1u << t, tmask = nelem - 1;
   const long long base = d.off;
-  const int R = t > 6 ? 1 << (t - 6) : 1;
-  const Params<T>& P = par[d.pset];
-  const int nl = k < 6 ? k : 6;
   const uint32_t xhi = H << t;
-  constexpr int NJ = (1 << TB) / BLOCK;      // states per thread
-  // step-B operands of this thread's states (perm order), fetched now so that their latency
-  // hides behind the table build and step A: state index and 1/(D - diag Q)
+  const bool joint = d.mode == JOINT;
+  constexpr int NJ = (1 << TB) / TSB;        // states per thread
+  constexpr int NW = TSB / 64;
+  // ---- step-B operands of this thread's states (perm order), fetched first so that their
+  // latency hides behind the table load and step A: state index and 1/(D - diag Q)
   const uint16_t* pm = perm + (size_t)t * (1 << TB);
   uint32_t px[NJ];
   T lid[NJ];
+  if (LIDGV) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const uint32_t idx = (uint32_t)tid + BLOCK * j;
-    px[j] = idx < nelem ? pm[idx] : 0u;
-    lid[j] = idx < nelem ? lidg[base + xhi + px[j]] : T(0);
-  }
-  for (int e = tid; e < k * 64; e += BLOCK) {
-    const int b = e >> 6, l = e & 63;
-    const int row = d.ev[b];
-    const int c = d.cls[b];
-    const int pc = c == CS ? CP : c;
-    T v = 1;
-    for (int bb = 0; bb < nl; ++bb)
-      if (bb != b && ((l >> bb) & 1) && d.cls[bb] == pc) v *= P.th[row][d.ev[bb]];
-    Ltab[e] = v;
-    if (l < R) {
-      T u = (c == CM) ? P.baseM[row] : P.baseP[row];
-      for (int bb = 6; bb < t; ++bb)
-        if (bb != b && ((l >> (bb - 6)) & 1) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
-      for (int bb = t; bb < k; ++bb)
-        if (bb != b && ((H >> (bb - t)) & 1u) && d.cls[bb] == pc) u *= P.th[row][d.ev[bb]];
-      Utab[e] = u;
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t idx = (uint32_t)tid + TSB * j;
+      px[j] = idx < nelem ? pm[idx] : 0u;
+      lid[j] = idx < nelem ? lidg[base + xhi + px[j]] : T(0);
+    }
+  } else {
+    const T* dP = tab + d.toff + rate_table_size(k);
+    const T* dM = dP + (1ll << __popc(d.maskP));
+    const T* dE = dM + (1ll << __popc(d.maskM));
+    const uint32_t cP = d.maskP & tmask, cM = d.maskM & tmask, cE = d.pairP & tmask;
+    const uint32_t hP = pext32(xhi, d.maskP & ~tmask) << __popc(cP);
+    const uint32_t hM = pext32(xhi, d.maskM & ~tmask) << __popc(cM);
+    const uint32_t hE = pext32(xhi, d.pairP & ~tmask) << __popc(cE);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t idx = (uint32_t)tid + TSB * j;
+      px[j] = idx < nelem ? pm[idx] : 0u;
+      const uint32_t xl = px[j], x = xhi | xl;
+      T v = 1;
+      if (idx < nelem) {
+        if ((x >> d.seedbit) & 1u) v = T(1) / (dP[hP | pext32(xl, cP)] + dM[hM | pext32(xl, cM)]);
+        else if (eq_noseed(d, x)) v = T(1) / dE[hE | pext32(xl, cE)];
+      }
+      lid[j] = v;      // seed = 0 states with PT != MT: no rates and zero right-hand side, y stays 0
     }
   }
-  __syncthreads();
+  tile_tables(d, tab, H, Ltab, Utab, yt);
 
   const int wave = tid >> 6, lane = tid & 63;
-  const bool joint = d.mode == JOINT;
   const uint32_t last = (1u << k) - 1u;
 
   // ---- step A: right-hand side + transitions that cross the tile boundary
   T acc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const uint32_t xl = ((uint32_t)(wave + WAVES * j) << 6) | (uint32_t)lane;
+    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
     T rv = 0;
     if (xl < nelem) {
       const uint32_t x = xhi | xl;
@@ -240,44 +361,51 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
       if (mh == 0) continue;                                   // stays inside the tile: step B
       if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;       // tile-uniform part of the condition
       const T Lb = Ltab[b * 64 + lane];
+      T nv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {                           // all neighbour loads in flight together
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int r = wave + WAVES * j;
+        const int r = wave + NW * j;
         const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-        if (xl >= nelem) continue;
-        if (TR ? (xl & ml) != 0 : (xl & ml) != ml) continue;
         const uint32_t x = xhi | xl;
         const bool ss = seed_set(d, x);
-        bool cond;
-        if (kind == 1) cond = !ss && eq_noseed(d, x);
-        else if (is_seed) cond = eq_noseed(d, x);
-        else cond = ss;
-        if (cond) acc[j] += Lb * Utab[b * 64 + r] * y[base + (x ^ mv)];
+        bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
+        if (kind == 1) cond = cond && !ss && eq_noseed(d, x);
+        else if (is_seed) cond = cond && eq_noseed(d, x);
+        else cond = cond && ss;
+        const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
+        acc[j] += cond ? term : T(0);
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const uint32_t xl = ((uint32_t)(wave + WAVES * j) << 6) | (uint32_t)lane;
+    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
     if (xl < nelem) yt[xl] = acc[j];
   }
   __syncthreads();
 
   // ---- step B: popcount-ordered substitution inside the tile
   const int* lv = lvl + t * (TB + 2);
-  const uint32_t pairP = d.pairP;
+  const uint32_t pairP = joint ? d.pairP : 0u;
+  const uint32_t lone = d.lone;
   const int seedb = joint ? d.seedbit : -1;
   for (int s = 0; s <= t; ++s) {
     const int level = TR ? t - s : s;
     const int beg = lv[level], end = lv[level + 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int idx = tid + BLOCK * j;
+      const int idx = tid + TSB * j;
       if (idx < beg || idx >= end) continue;
       const uint32_t xl = px[j];
       const uint32_t x = xhi | xl;
-      const bool ss = seed_set(d, x);
-      const bool e0x = eq_noseed(d, x);
+      const bool ss = !joint || (seedb >= 0 && ((x >> seedb) & 1u));
+      const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
+      const uint32_t lo = xl & 63u, ro = xl >> 6;
       T z = yt[xl];
       uint32_t todo = TR ? (~xl & tmask) : xl;
       while (todo) {
@@ -291,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
           mv = 3u << b;
           cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
         } else cond = false;
-        if (cond) z += Ltab[b * 64 + (xl & 63u)] * Utab[b * 64 + (xl >> 6)] * yt[xl ^ mv];
+        if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ mv];
       }
       yt[xl] = lid[j] * z;
     }
@@ -299,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) void k_tsolve(const Desc* __restrict__ descs
   }
 
   // ---- step C
-  for (uint32_t e = tid; e < nelem; e += BLOCK) y[base + xhi + e] = yt[e];
+  for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
 }
 
 // ------------------------------------------------------------------------------------
