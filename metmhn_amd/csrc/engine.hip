@@ -567,7 +567,7 @@ struct Engine : EngineBase {
           solve(true, LJ, qJ.p, use_jacobi ? lidgJ.p : nullptr, rhsJ.p, 0, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);
-          hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(BLOCK), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
+          hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(CMB), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
                              b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
@@ -695,7 +695,7 @@ struct Engine : EngineBase {
     m.c.alloc((size_t)a_size(m.d));
     m.e.alloc((size_t)3 * N * N);
     zero(m.c.p, a_size(m.d));
-    hipLaunchKernelGGL((k_class_marg<T>), dim3(m.ntiles), dim3(BLOCK), 2 * sizeof(T) << TB, stream, m.dd.p, m.map.p,
+    hipLaunchKernelGGL((k_class_marg<T>), dim3(m.ntiles), dim3(CMB), 2 * sizeof(T) << TB, stream, m.dd.p, m.map.p,
                        m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);

@@ -684,18 +684,21 @@ __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* _
 __device__ __forceinline__ long long class_block_size(int kc) { return (long long)(kc + 1) << kc; }
 
 // Tile formulation: one workgroup stages a tile of p and q in LDS and runs one phase per class.
-// In the phase of class c a thread owns one setting `own` of the tile's class-c bits and walks the
-// settings of the tile's other bits, so the sum over T is a register accumulation; partial sums of
-// tiles that differ only in the other class' high bits meet through atomics (A is zeroed per call).
+// Lane l of a wave always owns the states whose low 6 index bits are l (conflict-free LDS rows,
+// coalesced global rows).  A wave task = (slot, setting of the tile's upper class bits): the wave
+// walks the settings of the upper other-class bits (independent loads, unrolled), then folds the
+// other-class LANE bits with wave shuffles, and the lanes that remain add their partial sum to
+// A with one atomic each; partial sums of tiles that differ only in the other class' high bits
+// meet there (A is zeroed per call).
+constexpr int CMB = 512;                      // threads per workgroup of k_class_marg
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_class_marg(const Desc* __restrict__ dJ,
-                                                      const int2* __restrict__ map,
-                                                      const T* __restrict__ p,
-                                                      const T* __restrict__ q, T* A) {
+__global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
+                                                    const int2* __restrict__ map,
+                                                    const T* __restrict__ p,
+                                                    const T* __restrict__ q, T* A) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* pt = reinterpret_cast<T*>(smem);
   T* qt = pt + (1 << TB);
-  __shared__ T part[BLOCK];
   const Desc& d = dJ[map[blockIdx.x].x];
   const uint32_t H = (uint32_t)map[blockIdx.x].y;
   if (d.seedbit < 0) return;
@@ -706,63 +709,49 @@ __global__ __launch_bounds__(BLOCK) void k_class_marg(const Desc* __restrict__ d
   const uint32_t sbm = 1u << d.seedbit;
   if (d.seedbit >= t && !(xhi & sbm)) return;             // tile lies in the seed = 0 half
   const uint32_t sfix = d.seedbit < t ? sbm : 0u;         // seeding bit inside the tile: fixed to 1
-  const int tid = threadIdx.x;
-  for (uint32_t e = tid; e < nelem; e += BLOCK) { pt[e] = p[d.off + xhi + e]; qt[e] = q[d.off + xhi + e]; }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NWV = CMB / 64;
+  for (uint32_t e = tid; e < nelem; e += CMB) { pt[e] = p[d.off + xhi + e]; qt[e] = q[d.off + xhi + e]; }
   __syncthreads();
   const int kP = __popc(d.maskP);
+  const bool lane_ok = (uint32_t)lane < nelem && ((sfix & 63u) == 0 || ((uint32_t)lane & sfix));
   for (int c = 0; c < 2; ++c) {
     const uint32_t cmask = c == 0 ? d.maskP : d.maskM;
     const uint32_t cm = cmask & tmask;                    // class bits inside the tile
     const uint32_t fm = tmask & ~cm & ~sfix;              // bits summed over
-    const int nc = __popc(cm), nf = __popc(fm), kc = __popc(cmask);
+    const uint32_t cml = cm & 63u, cmu = cm >> 6, fml = fm & 63u, fmu = fm >> 6;
+    const uint32_t sfu = sfix >> 6;                       // seeding bit among the upper tile bits (or 0)
+    const int nc = __popc(cm), ncl = __popc(cml), kc = __popc(cmask);
+    const uint32_t nou = 1u << __popc(cmu), nfu = 1u << __popc(fmu);
     T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(kP));
-    // compact index of the tile's high class bits (pext keeps bit order: low bits first)
-    uint32_t shi = 0;
-    { uint32_t m = cmask & ~tmask; int pos = 0; while (m) { const uint32_t low = m & (0u - m); if (xhi & low) shi |= 1u << pos; ++pos; m ^= low; } }
-    const uint32_t no = 1u << nc;
-    const int gb = no >= BLOCK ? 0 : (8 - nc < nf ? 8 - nc : nf);   // log2 of thread groups per `own`
-    const uint32_t G = 1u << gb;
-    uint32_t glow = 0, mm = fm;
-    for (int i = 0; i < gb; ++i) { const uint32_t low = mm & (0u - mm); glow |= low; mm ^= low; }
-    const uint32_t fup = fm & ~glow;
-    const uint32_t cnt = 1u << (nf - gb);
-    const uint32_t items = no * G;
-    for (int slot = 0; slot <= kc; ++slot) {
+    const uint32_t shi = pext32(xhi, cmask & ~tmask);     // compact index of the tile's high class bits
+    const uint32_t own_l = pext32((uint32_t)lane, cml);
+    const bool writer = lane_ok && ((uint32_t)lane & fml) == 0;
+    const uint32_t ntask = (uint32_t)(kc + 1) * nou;
+    for (uint32_t task = wave; task < ntask; task += NWV) {
+      const int slot = (int)(task / nou);
+      const uint32_t ou = task % nou;
       uint32_t bitl = 0;
-      if (slot > 0) {
-        bitl = pdep32(1u << (slot - 1), cmask);
-        if (bitl & ~tmask & xhi) continue;                // bit already set in every state of the tile
-      }
+      if (slot > 0) bitl = pdep32(1u << (slot - 1), cmask);
+      const uint32_t ub = pdep32(ou, cmu) | sfu;           // upper tile bits of this task (class part + seeding)
+      if ((bitl & ~tmask & xhi) || (((bitl & tmask) >> 6) & ub)) continue;    // bit already set: no flow (wave-uniform)
       const bool hib = (bitl & ~tmask) != 0;              // neighbour lives in another tile
-      for (uint32_t w0 = 0; w0 < items; w0 += BLOCK) {
-        const uint32_t w = w0 + tid;
-        T acc = 0;
-        uint32_t own = 0;
-        const bool on = w < items;
-        if (on) {
-          own = w & (no - 1);
-          const uint32_t g = w >> nc;
-          const uint32_t xo = pdep32(own, cm) | pdep32(g, glow) | sfix;
-          if (!(xo & bitl)) {
-            uint32_t fu = 0;
-            for (uint32_t i = 0; i < cnt; ++i) {
-              const uint32_t xl = xo | fu;
-              const T qv = hib ? q[d.off + (xhi | bitl | xl)] : qt[xl | bitl];
-              acc += pt[xl] * qv;
-              fu = ((fu | ~fup) + 1u) & fup;
-            }
-          }
-        }
-        if (G > 1) {                                       // combine the groups that share `own`
-          __syncthreads();
-          part[tid] = acc;
-          __syncthreads();
-          if (on && (w >> nc) == 0) { for (uint32_t g = 1; g < G; ++g) acc += part[(g << nc) | own]; }
-        }
-        if (on && (G == 1 || (w >> nc) == 0) && acc != T(0)) {
-          const long long S = ((long long)shi << nc) | own;
-          atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -acc : acc);
-        }
+      const bool lane_on = lane_ok && !((uint32_t)lane & bitl);
+      T acc = 0;
+      uint32_t fu = 0;
+#pragma unroll 4
+      for (uint32_t i = 0; i < nfu; ++i) {
+        const uint32_t xl = ((ub | fu) << 6) | (uint32_t)lane;
+        const uint32_t xs = xl & tmask;
+        const T qv = hib ? q[d.off + (xhi | bitl | xs)] : qt[(xs | bitl) & tmask];
+        acc += pt[xs] * qv;
+        fu = ((fu | ~fmu) + 1u) & fmu;
+      }
+      if (!lane_on) acc = 0;
+      for (uint32_t m = fml; m; m &= m - 1) acc += __shfl_xor(acc, (int)(m & (0u - m)));
+      if (writer && lane_on && acc != T(0)) {
+        const long long S = ((long long)shi << nc) | ((long long)ou << ncl) | own_l;
+        atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -acc : acc);
       }
     }
   }
