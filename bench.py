@@ -107,7 +107,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -134,7 +135,7 @@ def main():
         return ro.score_and_grad_reg(params, dat, 0.5, ro.symmetric_penal, 1e-3)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +149,7 @@ def main():
         val, grad = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -191,7 +192,7 @@ def main():
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(n, a.patients, a.cpu_sample)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

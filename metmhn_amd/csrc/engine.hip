@@ -273,10 +273,10 @@ struct Engine : EngineBase {
     }
     const size_t lds = sweep_lds(maxk);
     if (tr)
-      hipLaunchKernelGGL((k_sweep<T, true>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
+      hipLaunchKernelGGL((k_sweep<T, true>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, d_par.p, p, y,
                          lidg, rhs, rhs_mode, scal, std::max(maxk, 1), tab);
     else
-      hipLaunchKernelGGL((k_sweep<T, false>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, y,
+      hipLaunchKernelGGL((k_sweep<T, false>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, d_par.p, p, y,
                          lidg, rhs, rhs_mode, scal, std::max(maxk, 1), tab);
     HIPCHECK(hipGetLastError());
     if (timed) HIPCHECK(hipEventRecord(e1, stream));

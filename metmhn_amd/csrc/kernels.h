@@ -166,14 +166,31 @@ __device__ __forceinline__ void tile_tables(const Desc& d, const T* __restrict__
 // rhs_mode: 0 dense vector, 1 scal[prob] * e_last, 2 e_0.  p and y may alias (in-place
 // Jacobi is exact after k+1 sweeps because Q_off is nilpotent and triangular).
 // ------------------------------------------------------------------------------------
+constexpr int KSB = 512;                     // threads per workgroup of k_sweep
+
+// tile-uniform classification of a tile of a joint space
+//   0: every state has seeding set (only PT / MT events, plus seeding into eq states)
+//   1: seed = 0 tile without any PT == MT state: Q_off has no entries here
+//   2: anything else (seeding bit inside the tile, or a seed = 0 tile with eq states): generic path
+__device__ __forceinline__ int tile_kind(const Desc& d, uint32_t xhi, int t) {
+  if (d.mode != JOINT) return 0;
+  if (d.seedbit < t) return 2;                      // includes "no seeding slot"
+  if (xhi & (1u << d.seedbit)) return 0;
+  const uint32_t hmask = ~((1u << t) - 1u);
+  if (xhi & d.lone & hmask) return 1;
+  const uint32_t pp = d.pairP & hmask & 0x7fffffffu;
+  if (((xhi & pp) << 1) != (xhi & (pp << 1))) return 1;
+  return 2;
+}
+
 template <typename T, bool TR>
-__global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
-                                                 const int2* __restrict__ map,
-                                                 const Params<T>* __restrict__ par, const T* p, T* y,
-                                                 const T* __restrict__ lidg,
-                                                 const T* __restrict__ rhs, int rhs_mode,
-                                                 const T* __restrict__ scal, int maxk,
-                                                 const T* __restrict__ tab) {
+__global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
+                                               const int2* __restrict__ map,
+                                               const Params<T>* __restrict__ par, const T* p, T* y,
+                                               const T* __restrict__ lidg,
+                                               const T* __restrict__ rhs, int rhs_mode,
+                                               const T* __restrict__ scal, int maxk,
+                                               const T* __restrict__ tab) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* tile = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -189,51 +206,134 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(const Desc* __restrict__ descs,
   const uint32_t nelem = 1u << t, tmask = nelem - 1;
   const long long base = d.off;
   const int R = t > 6 ? 1 << (t - 6) : 1;
-  const Params<T>& P = par[d.pset];
-
-  tile_tables(d, tab, H, Ltab, Utab, tile);
-  for (uint32_t e = tid; e < nelem; e += BLOCK) tile[e] = p[base + ((long long)H << t) + e];
-  __syncthreads();
-
+  const uint32_t xhi = H << t;
+  constexpr int NW = KSB / 64;
+  constexpr int NJ = 64 / NW;                  // rows per wave
   const int wave = tid >> 6, lane = tid & 63;
   const bool joint = d.mode == JOINT;
   const uint32_t last = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
-  for (int r = wave; r < R; r += WAVES) {
-    const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-    if (xl >= nelem) continue;
-    const uint32_t x = (H << t) | xl;
-    const bool ss = seed_set(d, x);
-    const bool e0x = eq_noseed(d, x);
-    T acc = 0;
-    for (int b = 0; b < k; ++b) {
-      const uint32_t bit = 1u << b;
-      const bool has = (x >> b) & 1u;
-      const int c = d.cls[b];
-      uint32_t nb = x ^ bit;
-      bool cond;
-      if (joint && c == CS) {
-        cond = (TR ? !has : has) && e0x;                     // seeding event (kronvec.py:434-496)
-      } else if (ss) {
-        cond = TR ? !has : has;                              // PT / MT event after seeding (:290-431)
-      } else if ((d.pairP >> b) & 1u) {
-        const uint32_t both = 3u << b;                       // synchronised event before seeding (:214-287)
-        nb = x ^ both;
-        cond = e0x && (TR ? (x & both) == 0 : (x & both) == both);
-      } else {
-        cond = false;
-      }
-      if (cond) {
-        const T v = ((nb >> t) == H) ? tile[nb & tmask] : p[base + nb];
-        acc += Ltab[b * 64 + lane] * Utab[b * 64 + r] * v;
+  const int kind = tile_kind(d, xhi, t);
+
+  // own states straight into registers (and into LDS for the row-bit neighbours)
+  T v[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+    v[j] = xl < nelem ? p[base + xhi + xl] : T(0);
+  }
+  tile_tables(d, tab, H, Ltab, Utab, tile);    // uses the tile area as scratch, ends with a barrier
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+    if (xl < nelem) tile[xl] = v[j];
+  }
+  __syncthreads();
+
+  T acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = 0;
+
+  if (kind == 0) {
+    // ---- fast path: every bit is a plain single-bit move
+    const int nlane = t < 6 ? t : 6;
+    // lane bits: neighbour = other lane of the same row (wave shuffle)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      if (b < nlane) {
+        const T Lb = Ltab[b * 64 + lane];
+        const bool has = (lane >> b) & 1;
+        const bool on = TR ? !has : has;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = wave + NW * j;
+          const T nb = __shfl_xor(v[j], 1 << b);
+          if (r < R) acc[j] += on ? Lb * Utab[b * 64 + r] * nb : T(0);
+        }
       }
     }
-    T out = acc;
+    // row bits: neighbour = same lane of another row of the tile (LDS, conflict-free)
+    for (int b = 6; b < t; ++b) {
+      const T Lb = Ltab[b * 64 + lane];
+      const int rb = 1 << (b - 6);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave + NW * j;
+        const bool has = (r & rb) != 0;
+        if (r < R && (TR ? !has : has)) acc[j] += Lb * Utab[b * 64 + r] * tile[((r ^ rb) << 6) | lane];
+      }
+    }
+    // tile bits: neighbour = same position of another tile (coalesced global rows, batched)
+    for (int b = t; b < k; ++b) {
+      const uint32_t bit = 1u << b;
+      const bool has = (xhi & bit) != 0;
+      const bool is_seed = joint && b == d.seedbit;
+      if (is_seed ? TR : (TR ? has : !has)) continue;     // seeding enters these tiles only in Q (not Q^T)
+      const T Lb = Ltab[b * 64 + lane];
+      T nv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        nv[j] = xl < nelem ? p[base + ((xhi | xl) ^ bit)] : T(0);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave + NW * j;
+        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+        const bool on = r < R && xl < nelem && (!is_seed || eq_noseed(d, xhi | xl));
+        acc[j] += on ? Lb * Utab[b * 64 + (r & 63)] * nv[j] : T(0);
+      }
+    }
+  } else if (kind == 2) {
+    // ---- generic path (seeding bit inside the tile, or seed = 0 tile with PT == MT states)
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+      const int r = wave + NW * j;
+      const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+      if (r >= R || xl >= nelem) continue;
+      const uint32_t x = xhi | xl;
+      const bool ss = seed_set(d, x);
+      const bool e0x = eq_noseed(d, x);
+      T a = 0;
+      for (int b = 0; b < k; ++b) {
+        const uint32_t bit = 1u << b;
+        const bool has = (x >> b) & 1u;
+        const int c = d.cls[b];
+        uint32_t nb = x ^ bit;
+        bool cond;
+        if (joint && c == CS) {
+          cond = (TR ? !has : has) && e0x;                     // seeding event (kronvec.py:434-496)
+        } else if (ss) {
+          cond = TR ? !has : has;                              // PT / MT event after seeding (:290-431)
+        } else if ((d.pairP >> b) & 1u) {
+          const uint32_t both = 3u << b;                       // synchronised event before seeding (:214-287)
+          nb = x ^ both;
+          cond = e0x && (TR ? (x & both) == 0 : (x & both) == both);
+        } else {
+          cond = false;
+        }
+        if (cond) {
+          const T nv = ((nb >> t) == H) ? tile[nb & tmask] : p[base + nb];
+          a += Ltab[b * 64 + lane] * Utab[b * 64 + r] * nv;
+        }
+      }
+      acc[j] = a;
+    }
+  }
+  // kind == 1: Q_off has no entries in this tile, acc stays 0
+
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int r = wave + NW * j;
+    const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+    if (r >= R || xl >= nelem) continue;
+    const uint32_t x = xhi | xl;
+    T out = acc[j];
     if (lidg) {
       T rv;
       if (rhs_mode == 0) rv = rhs[base + x];
       else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
       else rv = (x == 0) ? T(1) : T(0);
-      out = lidg[base + x] * (acc + rv);
+      out = lidg[base + x] * (acc[j] + rv);
     }
     y[base + x] = out;
   }

@@ -41,7 +41,10 @@ def allreduce_sums(sums: np.ndarray, group=None) -> np.ndarray:
     """Sum the partial-sum buffers of all ranks (no-op without an initialised process group)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return sums
+    if dist.get_world_size(group) == 1 and os.environ.get("MMHN_FORCE_ALLREDUCE") != "1":
         return sums
     t = torch.from_numpy(np.ascontiguousarray(sums, dtype=np.float64))
     if dist.get_backend(group) == "nccl":

@@ -57,7 +57,8 @@ def _engine_for(dat) -> Engine:
         eng = Engine(n_mut, device=dev, dtype=_OPTIONS["dtype"])
         rows = dat if world == 1 else dat[_dist.shard_rows(dat, world)[rank]]
         eng.set_cohort(rows)
-        eng._sharded = world > 1
+        # MMHN_FORCE_ALLREDUCE=1: run the collective even with one rank (exercises the RCCL path on a 1-GPU box)
+        eng._sharded = world > 1 or os.environ.get("MMHN_FORCE_ALLREDUCE") == "1"
         _CACHE[key] = eng
     return eng
 
