@@ -26,6 +26,18 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int DESC_WORDS = (sizeof(Desc) + 3) / 4;
 constexpr int DESC_PAD = ((sizeof(Desc) + 15) / 16) * 16;
 
+// XCD-aware block -> work-item mapping: workgroups are dealt round-robin over the 8 XCDs
+// (blockIdx % 8 shares an XCD, MI355X_MICROARCH.md), so give every XCD one contiguous chunk of the
+// list; consecutive tiles of one patient then share an L2.  Speed only, never correctness.
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
+#ifdef MMHN_NO_XCD_REMAP
+  return b;
+#else
+  const uint32_t q = n >> 3, rem = n & 7u, x = b & 7u, i = b >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
+#endif
+}
+
 __device__ __forceinline__ void load_desc(Desc* dst, const Desc* src) {
   const int* s = reinterpret_cast<const int*>(src);
   int* d = reinterpret_cast<int*>(dst);
@@ -197,8 +209,9 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
   T* Ltab = tile + (1 << TB);
   T* Utab = Ltab + maxk * 64;
   const int tid = threadIdx.x;
-  const int prob = map[blockIdx.x].x;
-  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x);
+  const int prob = map[blk].x;
+  const uint32_t H = (uint32_t)map[blk].y;
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = d.k;
@@ -385,8 +398,9 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
   T* Ltab = yt + (1 << TB);
   T* Utab = Ltab + maxk * 64;
   const int tid = threadIdx.x;
-  const int prob = lmap[blockIdx.x].x;
-  const uint32_t H = (uint32_t)lmap[blockIdx.x].y;
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x);
+  const int prob = lmap[blk].x;
+  const uint32_t H = (uint32_t)lmap[blk].y;
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = d.k;
@@ -799,8 +813,9 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   extern __shared__ __align__(16) unsigned char smem[];
   T* pt = reinterpret_cast<T*>(smem);
   T* qt = pt + (1 << TB);
-  const Desc& d = dJ[map[blockIdx.x].x];
-  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x);
+  const Desc& d = dJ[map[blk].x];
+  const uint32_t H = (uint32_t)map[blk].y;
   if (d.seedbit < 0) return;
   const int k = d.k;
   const int t = k < TB ? k : TB;
