@@ -1,0 +1,7 @@
+#!/bin/bash
+# usage: scripts/pmc_kv.sh <tag> <counter> <kv_only args...>
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+tag=$1; ctr=$2; shift; shift
+cd /tmp && rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $R/gpurun_out/$tag -- python3 $R/scripts/kv_only.py "$@" > $R/gpurun_out/$tag.log 2>&1
+tail -1 $R/gpurun_out/$tag.log
