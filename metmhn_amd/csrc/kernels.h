@@ -431,18 +431,30 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
     const uint32_t hP = pext32(xhi, d.maskP & ~tmask) << __popc(cP);
     const uint32_t hM = pext32(xhi, d.maskM & ~tmask) << __popc(cM);
     const uint32_t hE = pext32(xhi, d.pairP & ~tmask) << __popc(cE);
+    // pext of the 12 tile bits through two 64-entry tables per mask (low 6 / high 6 bits of xl)
+    uint32_t* pxt = reinterpret_cast<uint32_t*>(Utab);         // Utab is filled later by tile_tables
+    if (tid < 384) {
+      const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
+      const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
+      const uint32_t part = half == 0 ? pext32((uint32_t)v, m & 63u)
+                                      : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
+      pxt[tid] = part;
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t idx = (uint32_t)tid + TSB * j;
       px[j] = idx < nelem ? pm[idx] : 0u;
       const uint32_t xl = px[j], x = xhi | xl;
+      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
       T v = 1;
       if (idx < nelem) {
-        if ((x >> d.seedbit) & 1u) v = T(1) / (dP[hP | pext32(xl, cP)] + dM[hM | pext32(xl, cM)]);
-        else if (eq_noseed(d, x)) v = T(1) / dE[hE | pext32(xl, cE)];
+        if ((x >> d.seedbit) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
+        else if (eq_noseed(d, x)) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
       }
       lid[j] = v;      // seed = 0 states with PT != MT: no rates and zero right-hand side, y stays 0
     }
+    __syncthreads();   // pxt lives in the Utab area: done before tile_tables overwrites it
   }
   tile_tables(d, tab, H, Ltab, Utab, yt);
 
@@ -824,10 +836,13 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   const uint32_t sbm = 1u << d.seedbit;
   if (d.seedbit >= t && !(xhi & sbm)) return;             // tile lies in the seed = 0 half
   const uint32_t sfix = d.seedbit < t ? sbm : 0u;         // seeding bit inside the tile: fixed to 1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: task bookkeeping stays scalar
   constexpr int NWV = CMB / 64;
+  __shared__ uint32_t slotbit[34];                                 // index-bit mask of slot s (0 for the diagonal slot)
+  __shared__ uint32_t ubtab[64];                                   // upper tile bits of the ou-th class setting
+  __shared__ uint32_t futab[64];                                   // upper tile bits of the i-th other-class setting
   for (uint32_t e = tid; e < nelem; e += CMB) { pt[e] = p[d.off + xhi + e]; qt[e] = q[d.off + xhi + e]; }
-  __syncthreads();
   const int kP = __popc(d.maskP);
   const bool lane_ok = (uint32_t)lane < nelem && ((sfix & 63u) == 0 || ((uint32_t)lane & sfix));
   for (int c = 0; c < 2; ++c) {
@@ -838,35 +853,73 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
     const uint32_t sfu = sfix >> 6;                       // seeding bit among the upper tile bits (or 0)
     const int nc = __popc(cm), ncl = __popc(cml), kc = __popc(cmask);
     const uint32_t nou = 1u << __popc(cmu), nfu = 1u << __popc(fmu);
+    __syncthreads();                                      // tile staged / previous class done with the tables
+    if (tid <= kc) slotbit[tid] = tid == 0 ? 0u : pdep32(1u << (tid - 1), cmask);
+    if (tid >= 64 && tid < 64 + (int)nou) ubtab[tid - 64] = pdep32((uint32_t)(tid - 64), cmu) | sfu;
+    if (tid >= 128 && tid < 128 + (int)nfu) futab[tid - 128] = pdep32((uint32_t)(tid - 128), fmu);
+    __syncthreads();
     T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(kP));
     const uint32_t shi = pext32(xhi, cmask & ~tmask);     // compact index of the tile's high class bits
     const uint32_t own_l = pext32((uint32_t)lane, cml);
     const bool writer = lane_ok && ((uint32_t)lane & fml) == 0;
-    const uint32_t ntask = (uint32_t)(kc + 1) * nou;
+    // a task = (chunk of SC slots, upper class setting): one p load feeds SC independent q loads
+    constexpr int SC = 8;
+    const uint32_t nchunk = (uint32_t)(kc + 1 + SC - 1) / SC;
+    const uint32_t ntask = nchunk * nou;
     for (uint32_t task = wave; task < ntask; task += NWV) {
-      const int slot = (int)(task / nou);
+      const int s0 = (int)(task / nou) * SC;
       const uint32_t ou = task % nou;
-      uint32_t bitl = 0;
-      if (slot > 0) bitl = pdep32(1u << (slot - 1), cmask);
-      const uint32_t ub = pdep32(ou, cmu) | sfu;           // upper tile bits of this task (class part + seeding)
-      if ((bitl & ~tmask & xhi) || (((bitl & tmask) >> 6) & ub)) continue;    // bit already set: no flow (wave-uniform)
-      const bool hib = (bitl & ~tmask) != 0;              // neighbour lives in another tile
-      const bool lane_on = lane_ok && !((uint32_t)lane & bitl);
-      T acc = 0;
-      uint32_t fu = 0;
-#pragma unroll 4
-      for (uint32_t i = 0; i < nfu; ++i) {
-        const uint32_t xl = ((ub | fu) << 6) | (uint32_t)lane;
-        const uint32_t xs = xl & tmask;
-        const T qv = hib ? q[d.off + (xhi | bitl | xs)] : qt[(xs | bitl) & tmask];
-        acc += pt[xs] * qv;
-        fu = ((fu | ~fmu) + 1u) & fmu;
+      const uint32_t ub = ubtab[ou];                       // upper tile bits of this task (class part + seeding)
+      uint32_t bits[SC];
+      bool live[SC], hib[SC];
+#pragma unroll
+      for (int s = 0; s < SC; ++s) {
+        const int slot = s0 + s;
+        const uint32_t bl = slot <= kc ? slotbit[slot] : 0u;
+        bits[s] = bl;
+        // bit already set in every state of this task: no flow (wave-uniform)
+        live[s] = slot <= kc && !((bl & ~tmask & xhi) || (((bl & tmask) >> 6) & ub));
+        hib[s] = (bl & ~tmask) != 0;                        // neighbour lives in another tile
       }
-      if (!lane_on) acc = 0;
-      for (uint32_t m = fml; m; m &= m - 1) acc += __shfl_xor(acc, (int)(m & (0u - m)));
-      if (writer && lane_on && acc != T(0)) {
-        const long long S = ((long long)shi << nc) | ((long long)ou << ncl) | own_l;
-        atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -acc : acc);
+      T acc[SC];
+#pragma unroll
+      for (int s = 0; s < SC; ++s) acc[s] = 0;
+      // neighbours inside the tile: LDS
+      for (uint32_t i = 0; i < nfu; ++i) {
+        const uint32_t xs = (((ub | futab[i]) << 6) | (uint32_t)lane) & tmask;
+        const T pv = pt[xs];
+#pragma unroll
+        for (int s = 0; s < SC; ++s)
+          if (live[s] && !hib[s]) acc[s] += pv * qt[(xs | bits[s]) & tmask];
+      }
+      // neighbours in another tile: coalesced global rows, 8 loads in flight
+#pragma unroll
+      for (int s = 0; s < SC; ++s) {
+        if (!(live[s] && hib[s])) continue;
+        for (uint32_t i0 = 0; i0 < nfu; i0 += 8) {
+          T qv[8];
+          uint32_t xr[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u < nfu ? i0 + u : nfu - 1;
+            xr[u] = (((ub | futab[i]) << 6) | (uint32_t)lane) & tmask;
+            qv[u] = q[d.off + (xhi | bits[s] | xr[u])];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (i0 + u < nfu) acc[s] += pt[xr[u]] * qv[u];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < SC; ++s) {
+        if (!live[s]) continue;
+        T a = (lane_ok && !((uint32_t)lane & bits[s])) ? acc[s] : T(0);
+        for (uint32_t m = fml; m; m &= m - 1) a += __shfl_xor(a, (int)(m & (0u - m)));
+        if (writer && !((uint32_t)lane & bits[s]) && a != T(0)) {
+          const int slot = s0 + s;
+          const long long S = ((long long)shi << nc) | ((long long)ou << ncl) | own_l;
+          atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -a : a);
+        }
       }
     }
   }
