@@ -20,7 +20,10 @@
 
 namespace mmhn {
 
-constexpr int TB = 12;        // tile bits
+#ifndef MMHN_TB
+#define MMHN_TB 12
+#endif
+constexpr int TB = MMHN_TB;   // tile bits
 constexpr int BLOCK = 256;    // threads per workgroup
 constexpr int WAVES = BLOCK / 64;
 constexpr int DESC_WORDS = (sizeof(Desc) + 3) / 4;

@@ -221,3 +221,44 @@ def test_substitution_solver_matches_jacobi_iteration(monkeypatch):
     b = e2.cohort_sums(lt, dp, dm)
     e2.close()
     np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
+def test_learn_mhn_matches_oracle_optimizer():
+    """Drop-in under SciPy's L-BFGS-B (regularized_optimization.py:301-334): same optimum as the
+    same optimizer run on the CPU oracle's objective."""
+    import scipy.optimize as opt
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import synthetic
+    import metmhn_amd.regularized_optimization as ro
+    n = 4
+    dat = synthetic.mixed_cohort(n, 60, seed=21, p_event=0.35)
+    N = n + 1
+    th0 = np.diag(np.full(N, -1.0))
+    dp0, dm0 = np.zeros(N), np.zeros(N)
+    th, dp, dm = ro.learn_mhn(th0, dp0, dm0, dat, 0.3, ro.symmetric_penal, 0.05, opt_iter=200, opt_ftol=1e-10,
+                              opt_v=False)
+    x0 = np.concatenate((th0.flatten(), dp0, dm0))
+    ref = opt.minimize(fun=O.score_and_grad_reg, jac=True, x0=x0, method="L-BFGS-B",
+                       args=(dat, 0.3, O.symmetric_penal, 0.05), options={"maxiter": 200, "ftol": 1e-10})
+    got = np.concatenate((th.flatten(), dp, dm))
+    f_got = float(O.score_reg(got, dat, 0.3, O.symmetric_penal, 0.05))
+    assert abs(f_got - float(ref.fun)) < 1e-7 * max(1.0, abs(float(ref.fun)))
+    np.testing.assert_allclose(got, ref.x, atol=5e-4)
+
+
+def test_fp32_engine_close_to_fp64():
+    """dtype="f32" engine (BASELINE config 5 dtype) on a small cohort: looser tolerance by construction."""
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import Engine, synthetic, distributed as D
+    n = 6
+    lt, dp, dm = synthetic.random_params(n)
+    dat = np.vstack((synthetic.full_k_cohort(n, 6), synthetic.mixed_cohort(n, 40, seed=4)))
+    e = Engine(n, dtype="f32")
+    e.set_cohort(dat)
+    s, g, a, b = D.combine_sums(e.cohort_sums(lt, dp, dm), n + 1, 0.5)
+    e.close()
+    s2, g2, a2, b2 = O.score_and_grad(lt, dp, dm, dat, 0.5)
+    np.testing.assert_allclose(s, s2, rtol=2e-5)
+    np.testing.assert_allclose(g, g2, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(a, a2, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(b, b2, rtol=2e-3, atol=2e-5)
