@@ -57,6 +57,15 @@ struct Params {
   T dm[MAXN];          // exp(log_d_m)
 };
 
+// joint problem -> its marginal problems (right-hand side of the joint adjoint, likelihood.py:573-575, 617-618):
+// rhs_J[x] = sum over parts of cst[part] * q_S[part][upper half][pext(x, free mask)] on the compatible states
+template <typename T>
+struct JLink {
+  long long soff[2];   // offset of the marginal problem's vectors, -1 if the part is absent
+  int sk[2];           // its number of bits
+  T cst[2];            // D_p (part 0) / D_m (part 1) on the compatible states (constant there)
+};
+
 // one patient of a batch: which problems belong to it and how their results combine
 struct PatRec {
   int kind;            // dat type 0..3; 4 = all-zero type-0 row (closed form)

@@ -157,6 +157,7 @@ struct Engine : EngineBase {
   DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS, tabJ, tabS;
   int pi_owner = -1, qJ_owner = -1;   // batch whose (pruned) layout the zero-initialised buffers hold
   DevArr<double> lp, out, sums;
+  DevArr<JLink<T>> links;
   // popcount-ordered state permutations of every tile size (k_tsolve step B)
   DevArr<uint16_t> d_perm;
   DevArr<int> d_lvl;
@@ -358,10 +359,10 @@ struct Engine : EngineBase {
       const int beg = (*L.lof)[lev], cntl = (*L.lof)[lev + 1] - beg;
       if (cntl == 0) continue;
       // compulsory traffic of a tile: write y (+ read dense rhs, + read the lidg vector when there is one)
-      const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);
+      const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);   // modes 1-3: rhs is not a 2^k vector
       timed(per_tile * cntl, [&]() {
         const dim3 g(cntl), bk(TSB);
-#define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab
+#define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab, links.p, qS.p
         if (lidg) {
           if (tr) hipLaunchKernelGGL((k_tsolve<T, true, true>), g, bk, lds, stream, TS_ARGS);
           else hipLaunchKernelGGL((k_tsolve<T, false, true>), g, bk, lds, stream, TS_ARGS);
@@ -443,7 +444,7 @@ struct Engine : EngineBase {
       probe.vecJ = cur.vecJ + (hasJ ? (1ll << dj.k) : 0);
       probe.vecS = cur.vecS + (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
       probe.asize = cur.asize + (hasJ ? a_size(dj) : 0);
-      const size_t need = (size_t)(4 * probe.vecJ + 4 * probe.vecS + probe.asize + cur.tabJ + cur.tabS) * sizeof(T);
+      const size_t need = (size_t)((use_jacobi ? 4 : 2) * probe.vecJ + 4 * probe.vecS + probe.asize + cur.tabJ + cur.tabS) * sizeof(T);
       if (!cur.pats.empty() && need > ws_limit) flush();
       if (hasJ) {
         dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
@@ -492,8 +493,9 @@ struct Engine : EngineBase {
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
-    pi.alloc(mvJ); qJ.alloc(mvJ); rhsJ.alloc(mvJ);
-    if (use_jacobi) lidgJ.alloc(mvJ);
+    pi.alloc(mvJ); qJ.alloc(mvJ);
+    if (use_jacobi) { lidgJ.alloc(mvJ); rhsJ.alloc(mvJ); }
+    links.alloc(std::max<size_t>(mnJ, 1));
     tabJ.alloc(mtJ); tabS.alloc(mtS);
     pi_owner = qJ_owner = -1;
     rhsS.alloc(mvS); pS.alloc(mvS); lidgS.alloc(mvS); qS.alloc(mvS);
@@ -557,14 +559,18 @@ struct Engine : EngineBase {
           HIPCHECK(hipGetLastError());
         }
         if (nJ) {
-          // 5 joint adjoint
-          zero(rhsJ.p, b.vecJ);
+          // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
+          hipLaunchKernelGGL((k_links<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dJ.p,
+                             b.d_dS.p, d_par.p, links.p);
+          HIPCHECK(hipGetLastError());
+          if (use_jacobi) zero(rhsJ.p, b.vecJ);
           for (int part = 0; part < 2; ++part) {
             hipLaunchKernelGGL((k_scatter_marg<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
-                               b.d_dS.p, d_par.p, qS.p, rhsS.p, rhsJ.p, dots.p, part);
+                               b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part);
             HIPCHECK(hipGetLastError());
           }
-          solve(true, LJ, qJ.p, use_jacobi ? lidgJ.p : nullptr, rhsJ.p, 0, nullptr);
+          if (use_jacobi) solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
+          else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);
           hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(CMB), 2 * sizeof(T) << TB, stream, b.d_dJ.p,

@@ -394,7 +394,9 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
                                                 const T* __restrict__ scal,
                                                 const uint16_t* __restrict__ perm,
                                                 const int* __restrict__ lvl, int maxk,
-                                                const T* __restrict__ tab) {
+                                                const T* __restrict__ tab,
+                                                const JLink<T>* __restrict__ links,
+                                                const T* __restrict__ qS) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -419,6 +421,9 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
   const uint16_t* pm = perm + (size_t)t * (1 << TB);
   uint32_t px[NJ];
   T lid[NJ];
+  T rhs3[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) rhs3[j] = 0;
   if (LIDGV) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -457,6 +462,26 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
       }
       lid[j] = v;      // seed = 0 states with PT != MT: no rates and zero right-hand side, y stays 0
     }
+    if (rhs_mode == 3) {
+      // right-hand side of the joint adjoint, formed on the fly: only the compatible states (all bits of the
+      // observed tumour + seeding set) are non-zero and take D * q_marginal[pext(x, other tumour's bits)]
+      const JLink<T> L = links[prob];
+      const bool seed_hi = (xhi >> d.seedbit) & 1u;
+      const bool can0 = L.soff[0] >= 0 && (d.seedbit < t || seed_hi) && ((xhi & d.maskP & ~tmask) == (d.maskP & ~tmask));
+      const bool can1 = L.soff[1] >= 0 && (d.seedbit < t || seed_hi) && ((xhi & d.maskM & ~tmask) == (d.maskM & ~tmask));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)((tid >> 6) + NW * j) << 6) | (uint32_t)(tid & 63);
+        const uint32_t x = xhi | xl;
+        T rv = 0;
+        if (xl < nelem && ((x >> d.seedbit) & 1u)) {
+          const uint32_t lo = xl & 63u, hi6 = xl >> 6;
+          if (can0 && (xl & cP) == cP) rv += L.cst[0] * qS[L.soff[0] + (1ll << (L.sk[0] - 1)) + ((hM | pxt[128 + lo] | pxt[192 + hi6]))];
+          if (can1 && (xl & cM) == cM) rv += L.cst[1] * qS[L.soff[1] + (1ll << (L.sk[1] - 1)) + ((hP | pxt[lo] | pxt[64 + hi6]))];
+        }
+        rhs3[j] = rv;
+      }
+    }
     __syncthreads();   // pxt lives in the Utab area: done before tile_tables overwrites it
   }
   tile_tables(d, tab, H, Ltab, Utab, yt);
@@ -474,7 +499,8 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
       const uint32_t x = xhi | xl;
       if (rhs_mode == 0) rv = rhs[base + x];
       else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
-      else rv = (x == 0) ? T(1) : T(0);
+      else if (rhs_mode == 2) rv = (x == 0) ? T(1) : T(0);
+      else rv = rhs3[j];
     }
     acc[j] = rv;
   }
@@ -752,7 +778,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
   for (uint32_t e = threadIdx.x; e < half; e += BLOCK) {
     const uint32_t x = pdep32(e, free_) | fixed;
     const T qv = qS[ds.off + half + e];
-    rhsJ[dj.off + x] += c * qv;
+    if (rhsJ) rhsJ[dj.off + x] += c * qv;
     dot += qv * rhsS[ds.off + half + e];
   }
   red[threadIdx.x] = dot;
@@ -800,6 +826,25 @@ __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* _
     l += log(dr);
   }
   lp[i] = l;
+}
+
+// per paired patient: where the right-hand side of the joint adjoint comes from (rhs_mode 3 of k_tsolve)
+template <typename T>
+__global__ void k_links(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dJ,
+                        const Desc* __restrict__ dS, const Params<T>* __restrict__ par, JLink<T>* links) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npat) return;
+  const PatRec pr = pats[i];
+  if (pr.j < 0) return;
+  JLink<T> L;
+  for (int part = 0; part < 2; ++part) {
+    if (pr.s[part] >= 0) {
+      L.soff[part] = dS[pr.s[part]].off;
+      L.sk[part] = dS[pr.s[part]].k;
+      L.cst[part] = obs_const(dJ[pr.j], par[PS_THETA], part);
+    } else { L.soff[part] = -1; L.sk[part] = 0; L.cst[part] = 0; }
+  }
+  links[pr.j] = L;
 }
 
 // ------------------------------------------------------------------------------------
