@@ -864,7 +864,10 @@ __device__ __forceinline__ long long class_block_size(int kc) { return (long lon
 // other-class LANE bits with wave shuffles, and the lanes that remain add their partial sum to
 // A with one atomic each; partial sums of tiles that differ only in the other class' high bits
 // meet there (A is zeroed per call).
-constexpr int CMB = 512;                      // threads per workgroup of k_class_marg
+#ifndef MMHN_CMB
+#define MMHN_CMB 512
+#endif
+constexpr int CMB = MMHN_CMB;                      // threads per workgroup of k_class_marg
 template <typename T>
 __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
                                                     const int2* __restrict__ map,
