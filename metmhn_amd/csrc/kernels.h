@@ -913,40 +913,69 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
     const uint32_t shi = pext32(xhi, cmask & ~tmask);     // compact index of the tile's high class bits
     const uint32_t own_l = pext32((uint32_t)lane, cml);
     const bool writer = lane_ok && ((uint32_t)lane & fml) == 0;
-    // a task = (chunk of SC slots, upper class setting): one p load feeds SC independent q loads
+    // slot lists of this class for this tile: in-tile slots (diagonal + class bits inside the tile; neighbour in
+    // LDS) and high slots (class bits above the tile that are still clear in this tile; neighbour tile in HBM)
+    __shared__ int lslot[MAXK + 1], hslot[MAXK + 1];
+    __shared__ int nls, nhs;
+    __syncthreads();
+    if (tid == 0) {
+      int a = 0, h = 0;
+      for (int s = 0; s <= kc; ++s) {
+        const uint32_t bl = slotbit[s];
+        if ((bl & ~tmask) == 0) lslot[a++] = s;
+        else if (!(bl & xhi)) hslot[h++] = s;
+      }
+      nls = a; nhs = h;
+    }
+    __syncthreads();
     constexpr int SC = 8;
-    const uint32_t nchunk = (uint32_t)(kc + 1 + SC - 1) / SC;
-    const uint32_t ntask = nchunk * nou;
+    const int nl_ = nls, nh_ = nhs;
+    const uint32_t nchunk = (uint32_t)(nl_ + SC - 1) / SC;
+    const uint32_t ntask_l = nchunk * nou, ntask = ntask_l + (uint32_t)nh_ * nou;
     for (uint32_t task = wave; task < ntask; task += NWV) {
-      const int s0 = (int)(task / nou) * SC;
-      const uint32_t ou = task % nou;
-      const uint32_t ub = ubtab[ou];                       // upper tile bits of this task (class part + seeding)
-      uint32_t bits[SC];
-      bool live[SC], hib[SC];
+      if (task < ntask_l) {
+        // ---- LDS task: SC in-tile slots of one upper class setting; one p load feeds SC q loads
+        const int c0 = (int)(task / nou) * SC;
+        const uint32_t ou = task % nou;
+        const uint32_t ub = ubtab[ou];
+        uint32_t bits[SC];
+        bool live[SC];
 #pragma unroll
-      for (int s = 0; s < SC; ++s) {
-        const int slot = s0 + s;
-        const uint32_t bl = slot <= kc ? slotbit[slot] : 0u;
-        bits[s] = bl;
-        // bit already set in every state of this task: no flow (wave-uniform)
-        live[s] = slot <= kc && !((bl & ~tmask & xhi) || (((bl & tmask) >> 6) & ub));
-        hib[s] = (bl & ~tmask) != 0;                        // neighbour lives in another tile
-      }
-      T acc[SC];
+        for (int s = 0; s < SC; ++s) {
+          const bool in = c0 + s < nl_;
+          const uint32_t bl = in ? slotbit[lslot[in ? c0 + s : 0]] : 0u;
+          bits[s] = bl;
+          live[s] = in && !((bl >> 6) & ub);                // upper-tile class bit already set in this task: no flow
+        }
+        T acc[SC];
 #pragma unroll
-      for (int s = 0; s < SC; ++s) acc[s] = 0;
-      // neighbours inside the tile: LDS
-      for (uint32_t i = 0; i < nfu; ++i) {
-        const uint32_t xs = (((ub | futab[i]) << 6) | (uint32_t)lane) & tmask;
-        const T pv = pt[xs];
+        for (int s = 0; s < SC; ++s) acc[s] = 0;
+        for (uint32_t i = 0; i < nfu; ++i) {
+          const uint32_t xs = (((ub | futab[i]) << 6) | (uint32_t)lane) & tmask;
+          const T pv = pt[xs];
 #pragma unroll
-        for (int s = 0; s < SC; ++s)
-          if (live[s] && !hib[s]) acc[s] += pv * qt[(xs | bits[s]) & tmask];
-      }
-      // neighbours in another tile: coalesced global rows, 8 loads in flight
+          for (int s = 0; s < SC; ++s)
+            if (live[s]) acc[s] += pv * qt[(xs | bits[s]) & tmask];
+        }
 #pragma unroll
-      for (int s = 0; s < SC; ++s) {
-        if (!(live[s] && hib[s])) continue;
+        for (int s = 0; s < SC; ++s) {
+          if (!live[s]) continue;
+          T v = (lane_ok && !((uint32_t)lane & bits[s])) ? acc[s] : T(0);
+          for (uint32_t m = fml; m; m &= m - 1) v += __shfl_xor(v, (int)(m & (0u - m)));
+          if (writer && !((uint32_t)lane & bits[s]) && v != T(0)) {
+            const int slot = lslot[c0 + s];
+            const long long S = ((long long)shi << nc) | ((long long)ou << ncl) | own_l;
+            atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -v : v);
+          }
+        }
+      } else {
+        // ---- high-slot task: neighbour rows come from another tile (coalesced global rows, 8 in flight)
+        const uint32_t tt = task - ntask_l;
+        const int slot = hslot[tt / nou];
+        const uint32_t ou = tt % nou;
+        const uint32_t ub = ubtab[ou];
+        const uint32_t bl = slotbit[slot];
+        T acc = 0;
         for (uint32_t i0 = 0; i0 < nfu; i0 += 8) {
           T qv[8];
           uint32_t xr[8];
@@ -954,22 +983,17 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
           for (int u = 0; u < 8; ++u) {
             const uint32_t i = i0 + u < nfu ? i0 + u : nfu - 1;
             xr[u] = (((ub | futab[i]) << 6) | (uint32_t)lane) & tmask;
-            qv[u] = q[d.off + (xhi | bits[s] | xr[u])];
+            qv[u] = q[d.off + (xhi | bl | xr[u])];
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (i0 + u < nfu) acc[s] += pt[xr[u]] * qv[u];
+            if (i0 + u < nfu) acc += pt[xr[u]] * qv[u];
         }
-      }
-#pragma unroll
-      for (int s = 0; s < SC; ++s) {
-        if (!live[s]) continue;
-        T a = (lane_ok && !((uint32_t)lane & bits[s])) ? acc[s] : T(0);
-        for (uint32_t m = fml; m; m &= m - 1) a += __shfl_xor(a, (int)(m & (0u - m)));
-        if (writer && !((uint32_t)lane & bits[s]) && a != T(0)) {
-          const int slot = s0 + s;
+        T v = lane_ok ? acc : T(0);
+        for (uint32_t m = fml; m; m &= m - 1) v += __shfl_xor(v, (int)(m & (0u - m)));
+        if (writer && v != T(0)) {
           const long long S = ((long long)shi << nc) | ((long long)ou << ncl) | own_l;
-          atomicAdd(&out[((long long)slot << kc) + S], slot == 0 ? -a : a);
+          atomicAdd(&out[((long long)slot << kc) + S], v);
         }
       }
     }
