@@ -41,6 +41,12 @@ __device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
 #endif
 }
 
+// Forward solves start from E0 * e_0 instead of e_0: a power of two that keeps the deep states of large
+// spaces away from the fp32 underflow range (SURVEY.md 7 "fp32 at k=25"); exact, undone in the log-prob
+// (k_seeds) and invisible to the gradient, whose adjoint is seeded with 1 / score.  fp64 needs none.
+template <typename T> __host__ __device__ inline T e0_scale() { return T(1); }
+template <> __host__ __device__ inline float e0_scale<float>() { return 1.152921504606846976e18f; }   // 2^60
+
 __device__ __forceinline__ void load_desc(Desc* dst, const Desc* src) {
   const int* s = reinterpret_cast<const int*>(src);
   int* d = reinterpret_cast<int*>(dst);
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
       T rv;
       if (rhs_mode == 0) rv = rhs[base + x];
       else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
-      else rv = (x == 0) ? T(1) : T(0);
+      else rv = (x == 0) ? e0_scale<T>() : T(0);
       out = lidg[base + x] * (acc[j] + rv);
     }
     y[base + x] = out;
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
       const uint32_t x = xhi | xl;
       if (rhs_mode == 0) rv = rhs[base + x];
       else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
-      else if (rhs_mode == 2) rv = (x == 0) ? T(1) : T(0);
+      else if (rhs_mode == 2) rv = (x == 0) ? e0_scale<T>() : T(0);
       else rv = rhs3[j];
     }
     acc[j] = rv;
@@ -796,7 +802,7 @@ __global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npat) return;
   const PatRec pr = pats[i];
-  if (pr.kind <= 2 && pr.s[0] >= 0) rhsS[dS[pr.s[0]].off] = T(1);
+  if (pr.kind <= 2 && pr.s[0] >= 0) rhsS[dS[pr.s[0]].off] = e0_scale<T>();
 }
 
 // per patient: total marginal score, adjoint seeds 1/score for its single problems, log-prob
@@ -816,7 +822,7 @@ __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* _
     }
   for (int part = 0; part < 2; ++part)
     if (pr.s[part] >= 0) seedS[pr.s[part]] = T(1) / full;
-  double l = log((double)full);
+  double l = log((double)full) - log((double)e0_scale<T>());
   if (pr.kind == 2) {   // likelihood.py:438: log(pTh[-1] * d_rates[-1]), last state has seeding set
     const Desc& ds = dS[pr.s[0]];
     const Params<T>& P = par[PS_THETA];

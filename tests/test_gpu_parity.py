@@ -262,3 +262,23 @@ def test_fp32_engine_close_to_fp64():
     np.testing.assert_allclose(g, g2, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(a, a2, rtol=2e-3, atol=2e-5)
     np.testing.assert_allclose(b, b2, rtol=2e-3, atol=2e-5)
+
+
+def test_fp32_engine_tracks_fp64_engine_on_large_spaces():
+    """No CPU oracle finishes k = 18 in seconds: compare the fp32 engine (e_0 pre-scaled by 2^60) with the
+    fp64 engine on the same paired patients; log-probs to 1e-4, gradients to 1e-2 of their norm."""
+    from metmhn_amd import Engine, synthetic
+    n = 18
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 6)
+    res = []
+    for dt in ("f64", "f32"):
+        e = Engine(n, dtype=dt)
+        e.set_cohort(dat)
+        res.append(e.patient_grads(lt, dp, dm))
+        e.close()
+    (lp64, g64, a64, b64), (lp32, g32, a32, b32) = res
+    assert np.all(np.isfinite(lp32)) and np.all(np.isfinite(g32))
+    np.testing.assert_allclose(lp32, lp64, rtol=1e-4)
+    for x32, x64 in ((g32, g64), (a32, a64), (b32, b64)):
+        assert np.linalg.norm(x32 - x64) <= 1e-2 * np.linalg.norm(x64)
