@@ -146,3 +146,36 @@ def test_synthetic_generators():
     m = synthetic.mixed_cohort(5, 200, seed=2)
     assert set(np.unique(m[:, -1])) == {0, 1, 2, 3}
     assert (m[m[:, -1] == 0, -3] == 0).all() and (m[m[:, -1] != 0, -3] == 1).all()
+
+
+def test_indep_matches_reference(golden):
+    from metmhn_amd.Utilityfunctions import indep
+    g = golden("cohorts")
+    for c in range(int(g["n_cases"])):
+        th, dp, dm = indep(g[f"c{c}_dat"])
+        np.testing.assert_allclose(th, g[f"c{c}_indep_theta"], rtol=1e-13, atol=0)
+        assert not dp.any() and not dm.any()
+
+
+def test_load_cohort_roundtrip(tmp_path):
+    """CSV -> dat labelling of examples/analysis.py:49-83 on a hand-made 5-row table."""
+    import pandas as pd
+    from metmhn_amd.Utilityfunctions import load_cohort, save_params
+    ev = pd.DataFrame({"Unnamed: 0": ["a", "b", "c", "d", "e"],
+                       "P.X (M)": [1, 0, 0, 1, 1], "M.X (M)": [0, 0, 1, 1, 0],
+                       "P.Y (M)": [0, 1, 0, 1, 0], "M.Y (M)": [0, 0, 0, 0, 1],
+                       "P.AgeAtSeqRep": [50, 60, "No primary included", 40, 55],
+                       "M.AgeAtSeqRep": ["No metastasis included", "No metastasis included", 70, 45, 50],
+                       "paired": [0, 0, 0, 1, 1]})
+    an = pd.DataFrame({"patientID": ["a", "b", "c", "d", "e"],
+                       "metaStatus": ["absent", "present", "isMetastasis", "present", "unknown"]})
+    ev.to_csv(tmp_path / "ev.csv", index=False)
+    an.to_csv(tmp_path / "an.csv", index=False)
+    dat, events = load_cohort(str(tmp_path / "ev.csv"), str(tmp_path / "an.csv"))
+    assert events == ["X (M)", "Y (M)", "Seeding"]
+    exp = np.array([[1, 0, 0, 0, 0, -99, 0], [0, 0, 1, 0, 1, -99, 1], [0, 1, 0, 0, 1, -99, 2],
+                    [1, 1, 1, 0, 1, 1, 3], [1, 0, 0, 1, 1, 2, 3]], dtype=np.int8)
+    assert np.array_equal(dat, exp)
+    save_params(str(tmp_path / "p.csv"), np.eye(3), np.zeros(3), np.ones(3), events)
+    back = pd.read_csv(tmp_path / "p.csv", index_col=0)
+    assert back.shape == (5, 3)

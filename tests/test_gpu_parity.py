@@ -282,3 +282,22 @@ def test_fp32_engine_tracks_fp64_engine_on_large_spaces():
     np.testing.assert_allclose(lp32, lp64, rtol=1e-4)
     for x32, x64 in ((g32, g64), (a32, a64), (b32, b64)):
         assert np.linalg.norm(x32 - x64) <= 1e-2 * np.linalg.norm(x64)
+
+
+def test_cross_val_workflow():
+    """Utilityfunctions.cross_val (:186-231) on the engine: shape, finiteness, and each cell equals the
+    held-out oracle score of the parameters learn_mhn returns for that fold."""
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import synthetic
+    import metmhn_amd.regularized_optimization as ro
+    import metmhn_amd.Utilityfunctions as U
+    n = 3
+    dat = synthetic.mixed_cohort(n, 40, seed=11, p_event=0.4)
+    lams = np.array([1e-2, 1e-1])
+    res = U.cross_val(dat, ro.symmetric_penal, lams, 2, 0.3, key=5)
+    assert res.shape == (2, 2) and np.isfinite(res.to_numpy()).all()
+    shuffled = dat[np.random.default_rng(5).permutation(dat.shape[0])]
+    train, test = shuffled[20:], shuffled[:20]
+    th0, dp0, dm0 = U.indep(train)
+    th, dp, dm = ro.learn_mhn(th0, dp0, dm0, train, 0.3, ro.symmetric_penal, lams[0], opt_v=False)
+    np.testing.assert_allclose(res.iloc[0, 0], O.score(th, dp, dm, test, 0.3), rtol=1e-8)

@@ -197,6 +197,8 @@ def _cohort_entry(out, pre, lt, dp, dm, dat, perc_met, lam):
     out[pre + "reg_value_only"] = np.float64(ro.score_reg(params, J(dat), perc_met, ro.symmetric_penal, lam))
     pen, pen_ = ro.symmetric_penal(params, lt.shape[0])
     out[pre + "pen"], out[pre + "pen_grad"] = np.float64(pen), A(pen_)
+    th_i, dp_i, dm_i = ru.indep(J(dat))                      # Utilityfunctions.py:157-183
+    out[pre + "indep_theta"], out[pre + "indep_dp"], out[pre + "indep_dm"] = A(th_i), A(dp_i), A(dm_i)
 
 
 def cohorts():
