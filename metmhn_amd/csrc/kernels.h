@@ -569,18 +569,34 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
       const uint32_t lo = xl & 63u, ro = xl >> 6;
       T z = yt[xl];
       uint32_t todo = TR ? (~xl & tmask) : xl;
+      // three bits per trip: their 9 LDS loads are issued together (unconditional, clamped addresses)
       while (todo) {
-        const int b = __ffs(todo) - 1;
-        todo &= todo - 1;
-        uint32_t mv = 1u << b;
-        bool cond;
-        if (b == seedb) cond = e0x;
-        else if (ss) cond = true;
-        else if ((pairP >> b) & 1u) {
-          mv = 3u << b;
-          cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
-        } else cond = false;
-        if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ mv];
+        int bb[3];
+        bool on[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          on[u] = todo != 0;
+          bb[u] = on[u] ? __ffs(todo) - 1 : 0;
+          todo &= todo - 1;                                   // 0 stays 0
+        }
+        T r[3];
+        bool cond[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int b = bb[u];
+          uint32_t mv = 1u << b;
+          bool c;
+          if (b == seedb) c = e0x;
+          else if (ss) c = true;
+          else if ((pairP >> b) & 1u) {
+            mv = 3u << b;
+            c = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
+          } else c = false;
+          cond[u] = c && on[u];
+          r[u] = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) z += cond[u] ? r[u] : T(0);
       }
       yt[xl] = lid[j] * z;
     }
