@@ -550,53 +550,55 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
   }
   __syncthreads();
 
-  // ---- step B: popcount-ordered substitution inside the tile
-  const int* lv = lvl + t * (TB + 2);
+  // ---- step B: popcount-ordered substitution inside the tile (a state's level is its popcount)
   const uint32_t pairP = joint ? d.pairP : 0u;
   const uint32_t lone = d.lone;
   const int seedb = joint ? d.seedbit : -1;
+  // fast tiles: every in-tile bit is a plain single-bit move for every state (single-tumour spaces, and
+  // joint tiles whose seeding bit lies above the tile and is set) - no per-bit condition logic at all
+  const bool fast = !joint || (seedb >= t && ((xhi >> seedb) & 1u));
+  int plev[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) plev[j] = ((uint32_t)tid + TSB * j) < nelem ? __popc(px[j]) : -1;
   for (int s = 0; s <= t; ++s) {
     const int level = TR ? t - s : s;
-    const int beg = lv[level], end = lv[level + 1];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int idx = tid + TSB * j;
-      if (idx < beg || idx >= end) continue;
+      if (plev[j] != level) continue;
       const uint32_t xl = px[j];
-      const uint32_t x = xhi | xl;
-      const bool ss = !joint || (seedb >= 0 && ((x >> seedb) & 1u));
-      const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
       const uint32_t lo = xl & 63u, ro = xl >> 6;
       T z = yt[xl];
       uint32_t todo = TR ? (~xl & tmask) : xl;
-      // three bits per trip: their 9 LDS loads are issued together (unconditional, clamped addresses)
-      while (todo) {
-        int bb[3];
-        bool on[3];
+      if (fast) {
+        while (todo) {                         // three bits per trip: their 9 LDS loads are issued together
+          T r[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          on[u] = todo != 0;
-          bb[u] = on[u] ? __ffs(todo) - 1 : 0;
-          todo &= todo - 1;                                   // 0 stays 0
+          for (int u = 0; u < 3; ++u) {
+            const bool on = todo != 0;
+            const int b = on ? __ffs(todo) - 1 : 0;
+            todo &= todo - 1;                  // 0 stays 0
+            const T v = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ (1u << b)];
+            r[u] = on ? v : T(0);
+          }
+          z += r[0] + r[1] + r[2];
         }
-        T r[3];
-        bool cond[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int b = bb[u];
+      } else {
+        const uint32_t x = xhi | xl;
+        const bool ss = seedb >= 0 && ((x >> seedb) & 1u);
+        const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
+        while (todo) {
+          const int b = __ffs(todo) - 1;
+          todo &= todo - 1;
           uint32_t mv = 1u << b;
-          bool c;
-          if (b == seedb) c = e0x;
-          else if (ss) c = true;
+          bool cond;
+          if (b == seedb) cond = e0x;
+          else if (ss) cond = true;
           else if ((pairP >> b) & 1u) {
             mv = 3u << b;
-            c = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
-          } else c = false;
-          cond[u] = c && on[u];
-          r[u] = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
+            cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
+          } else cond = false;
+          if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
         }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) z += cond[u] ? r[u] : T(0);
       }
       yt[xl] = lid[j] * z;
     }
