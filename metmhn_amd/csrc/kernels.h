@@ -442,10 +442,8 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
     const T* dM = dP + (1ll << __popc(d.maskP));
     const T* dE = dM + (1ll << __popc(d.maskM));
     const uint32_t cP = d.maskP & tmask, cM = d.maskM & tmask, cE = d.pairP & tmask;
-    const uint32_t hP = pext32(xhi, d.maskP & ~tmask) << __popc(cP);
-    const uint32_t hM = pext32(xhi, d.maskM & ~tmask) << __popc(cM);
-    const uint32_t hE = pext32(xhi, d.pairP & ~tmask) << __popc(cE);
-    // pext of the 12 tile bits through two 64-entry tables per mask (low 6 / high 6 bits of xl)
+    // pext of the 12 tile bits through two 64-entry tables per mask (low 6 / high 6 bits of xl);
+    // entries 384..386: compact index of the tile's high class bits (tile-uniform, computed once)
     uint32_t* pxt = reinterpret_cast<uint32_t*>(Utab);         // Utab is filled later by tile_tables
     if (tid < 384) {
       const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
@@ -453,8 +451,12 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
       const uint32_t part = half == 0 ? pext32((uint32_t)v, m & 63u)
                                       : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
       pxt[tid] = part;
+    } else if (tid < 387) {
+      const uint32_t m = tid == 384 ? d.maskP : tid == 385 ? d.maskM : d.pairP;
+      pxt[tid] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
     }
     __syncthreads();
+    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t idx = (uint32_t)tid + TSB * j;
@@ -917,6 +919,7 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   __shared__ uint32_t slotbit[34];                                 // index-bit mask of slot s (0 for the diagonal slot)
   __shared__ uint32_t ubtab[64];                                   // upper tile bits of the ou-th class setting
   __shared__ uint32_t futab[64];                                   // upper tile bits of the i-th other-class setting
+  __shared__ uint32_t shi_sh;
   for (uint32_t e = tid; e < nelem; e += CMB) { pt[e] = p[d.off + xhi + e]; qt[e] = q[d.off + xhi + e]; }
   const int kP = __popc(d.maskP);
   const bool lane_ok = (uint32_t)lane < nelem && ((sfix & 63u) == 0 || ((uint32_t)lane & sfix));
@@ -932,10 +935,17 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
     if (tid <= kc) slotbit[tid] = tid == 0 ? 0u : pdep32(1u << (tid - 1), cmask);
     if (tid >= 64 && tid < 64 + (int)nou) ubtab[tid - 64] = pdep32((uint32_t)(tid - 64), cmu) | sfu;
     if (tid >= 128 && tid < 128 + (int)nfu) futab[tid - 128] = pdep32((uint32_t)(tid - 128), fmu);
+    if (tid == 192) shi_sh = pext32(xhi, cmask & ~tmask);
     __syncthreads();
     T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(kP));
-    const uint32_t shi = pext32(xhi, cmask & ~tmask);     // compact index of the tile's high class bits
-    const uint32_t own_l = pext32((uint32_t)lane, cml);
+    const uint32_t shi = shi_sh;                          // compact index of the tile's high class bits
+    uint32_t own_l = 0;                                   // pext(lane, cml): 6 fixed steps
+    {
+      int pos = 0;
+#pragma unroll
+      for (int b6 = 0; b6 < 6; ++b6)
+        if ((cml >> b6) & 1u) { own_l |= (((uint32_t)lane >> b6) & 1u) << pos; ++pos; }
+    }
     const bool writer = lane_ok && ((uint32_t)lane & fml) == 0;
     // slot lists of this class for this tile: in-tile slots (diagonal + class bits inside the tile; neighbour in
     // LDS) and high slots (class bits above the tile that are still clear in this tile; neighbour tile in HBM)
