@@ -23,3 +23,13 @@ def R_inv_vec(log_theta, x, state, d_rates=1, transpose: bool = False):
 def x_partial_Q_y(log_theta, x, y, state):
     """vanilla.py:328-393: (val, d_diag)."""
     return engine(_n(state)).v_x_partial_Q_y(log_theta, x, y, state)
+
+
+def gradient(log_theta, state, p_0):
+    """vanilla.py:396-418: (d_theta, d_diag, p_theta) with p_theta = R^-1 p_0, x = R^-T e_last / p_theta[-1]."""
+    p_theta = R_inv_vec(log_theta, p_0, state)
+    x = np.zeros_like(p_theta)
+    x[-1] = 1.0 / p_theta[-1]
+    x = R_inv_vec(log_theta, x, state, transpose=True)
+    d_th, d_diag = x_partial_Q_y(log_theta, x, p_theta, state)
+    return d_th, d_diag, p_theta

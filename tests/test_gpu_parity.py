@@ -301,3 +301,91 @@ def test_cross_val_workflow():
     th0, dp0, dm0 = U.indep(train)
     th, dp, dm = ro.learn_mhn(th0, dp0, dm0, train, 0.3, ro.symmetric_penal, lams[0], opt_v=False)
     np.testing.assert_allclose(res.iloc[0, 0], O.score(th, dp, dm, test, 0.3), rtol=1e-8)
+
+
+def _row(n, pt, mt, order):
+    r = np.zeros(2 * n + 3, dtype=np.int8)
+    for j in pt:
+        r[2 * j] = 1
+    for j in mt:
+        r[2 * j + 1] = 1
+    r[2 * n], r[2 * n + 1], r[2 * n + 2] = 1, order, 3
+    return r
+
+
+def test_awkward_layouts_substitution_vs_jacobi(monkeypatch):
+    """Multi-tile joint spaces (k = 13..19) with skewed layouts: only PT bits, only MT bits, all events
+    paired (many PT == MT states, pair straddling the 2^12 tile boundary), lone-heavy, mixed.  The default
+    engine (pruned tile lists, class-table diagonal, on-the-fly adjoint right-hand side) must agree with the
+    Jacobi path (every tile, vector diagonal, dense right-hand side) and, for the smallest, with the oracle."""
+    from oracle import metmhn_oracle as O
+    from metmhn_amd import Engine, synthetic
+    n = 12
+    lt, dp, dm = synthetic.random_params(n, seed=5)
+    rows = [
+        _row(n, range(12), [], 1), _row(n, range(12), [], 0),                  # k = 13, PT only
+        _row(n, [], range(12), 2), _row(n, [], range(12), 0),                  # k = 13, MT only
+        _row(n, range(8), range(8), 0), _row(n, range(9), range(9), 1),        # k = 17 / 19, all paired
+        _row(n, range(6), range(6, 12), 2), _row(n, range(6), range(6, 12), 0),  # k = 13, all lone
+        _row(n, [0, 1, 2, 3, 4, 5, 6], [5, 6, 7, 8, 9, 10, 11], -99),          # k = 15, pair at bits 10..13
+        _row(n, [0, 2, 4, 5, 6, 7, 8, 9, 11], [1, 3, 5, 6, 10], 0),            # k = 15 mixed
+        _row(n, range(1), range(12), 1), _row(n, range(11), [11], 2),          # very skewed class sizes
+    ]
+    dat = np.array(rows, dtype=np.int8)
+    e1 = Engine(n)
+    e1.set_cohort(dat)
+    a = e1.patient_grads(lt, dp, dm)
+    e1.close()
+    monkeypatch.setenv("MMHN_SOLVER", "jacobi")
+    e2 = Engine(n)
+    e2.set_cohort(dat)
+    b = e2.patient_grads(lt, dp, dm)
+    e2.close()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+    lp, g, gp, gm, _ = O.patient_grad(lt, dp, dm, dat[6])                      # k = 13 oracle cross-check
+    np.testing.assert_allclose(a[0][6], lp, rtol=1e-10)
+    np.testing.assert_allclose(a[1][6], g, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[2][6], gp, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[3][6], gm, rtol=1e-8, atol=1e-10)
+
+
+def test_per_patient_reference_entry_points(golden):
+    """ssr._g_coupled_* / _lp_* / _grad_*_obs and mhn.gradient mirrors (reference argument orders)."""
+    from metmhn_amd.jx import likelihood as L, vanilla as V
+    g = golden("patients")
+    lt, dp, dm, dat = g["c0_log_theta"], g["c0_log_d_p"], g["c0_log_d_m"], g["c0_dat"]
+    n = (dat.shape[1] - 3) // 2
+    seen = set()
+    for r, row in enumerate(dat):
+        typ, order = int(row[-1]), int(row[-2])
+        key = (typ, order if typ == 3 else 0)
+        if key in seen or (typ == 0 and row[:-2].sum() == 0):
+            continue
+        seen.add(key)
+        st = row[:2 * n + 1]
+        if typ == 3:
+            fn_g = {0: L._g_coupled_0, 1: L._g_coupled_1}.get(order, L._g_coupled_2)
+            fn_l = {0: L._lp_coupled_0, 1: L._lp_coupled_1}.get(order, L._lp_coupled_2)
+            n_prim, n_met = int(st[::2].sum()), int(st[1::2].sum() + 1)
+            lp, gth, gdp, gdm = fn_g(lt, dp, dm, st, n_prim, n_met)
+            np.testing.assert_allclose(fn_l(lt, dp, dm, st, n_prim, n_met), g["c0_lp_score"][r], **TIGHT)
+            np.testing.assert_allclose(gdm, g["c0_d_dm"][r], **TIGHT)
+        elif typ == 2:
+            sm = np.append(st[1::2], 1)
+            lp, gth, gdp, gdm = L._grad_met_obs(lt, dp, dm, sm, int(sm.sum()))
+            np.testing.assert_allclose(L._lp_met_obs(lt, dp, dm, sm, int(sm.sum())), g["c0_lp_score"][r], **TIGHT)
+            np.testing.assert_allclose(gdm, g["c0_d_dm"][r], **TIGHT)
+        else:
+            sp = st[0::2]
+            lp, gth, gdp = L._grad_prim_obs(lt, dp, sp, int(sp.sum()))
+            np.testing.assert_allclose(L._lp_prim_obs(lt, dp, sp, int(sp.sum())), g["c0_lp_score"][r], **TIGHT)
+        np.testing.assert_allclose(lp, g["c0_lp_grad"][r], **TIGHT)
+        np.testing.assert_allclose(gth, g["c0_d_th"][r], **TIGHT)
+        np.testing.assert_allclose(gdp, g["c0_d_dp"][r], **TIGHT)
+    assert len(seen) >= 7
+    gv = golden("vanilla")
+    d_th, d_diag, pth = V.gradient(gv["c4_log_theta"], gv["c4_state"], gv["c4_p0"])
+    np.testing.assert_allclose(d_th, gv["c4_grad_th"], **TIGHT)
+    np.testing.assert_allclose(d_diag, gv["c4_grad_ddiag"], **TIGHT)
+    np.testing.assert_allclose(pth, gv["c4_grad_pth"], **TIGHT)
