@@ -187,7 +187,10 @@ __device__ __forceinline__ void tile_tables(const Desc& d, const T* __restrict__
 // rhs_mode: 0 dense vector, 1 scal[prob] * e_last, 2 e_0.  p and y may alias (in-place
 // Jacobi is exact after k+1 sweeps because Q_off is nilpotent and triangular).
 // ------------------------------------------------------------------------------------
-constexpr int KSB = 512;                     // threads per workgroup of k_sweep
+#ifndef MMHN_KSB
+#define MMHN_KSB 512
+#endif
+constexpr int KSB = MMHN_KSB;                     // threads per workgroup of k_sweep
 
 // tile-uniform classification of a tile of a joint space
 //   0: every state has seeding set (only PT / MT events, plus seeding into eq states)
@@ -236,20 +239,23 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
   const uint32_t last = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
   const int kind = tile_kind(d, xhi, t);
 
-  // own states straight into registers (and into LDS for the row-bit neighbours)
+  // own states straight into registers (and into LDS for the row-bit neighbours); rows of Q_off that are
+  // identically zero (kind 1) need neither p nor the rate tables
   T v[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-    v[j] = xl < nelem ? p[base + xhi + xl] : T(0);
+    v[j] = (kind != 1 && xl < nelem) ? p[base + xhi + xl] : T(0);
   }
-  tile_tables(d, tab, H, Ltab, Utab, tile);    // uses the tile area as scratch, ends with a barrier
+  if (kind != 1) {                             // tile-uniform branch
+    tile_tables(d, tab, H, Ltab, Utab, tile);  // uses the tile area as scratch, ends with a barrier
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-    if (xl < nelem) tile[xl] = v[j];
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+      if (xl < nelem) tile[xl] = v[j];
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   T acc[NJ];
 #pragma unroll
