@@ -86,6 +86,11 @@ struct Batch {
   // tiles sorted by level = popcount(tile index) for the substitution solver; lof* = level offsets
   std::vector<int2> lmapJ, lmapS;
   std::vector<int> lofJ, lofS;
+  // live tiles of every joint problem in index order (k_psolve: one workgroup per patient)
+  std::vector<int> ptoff;
+  std::vector<uint16_t> ptiles;
+  DevArr<int> d_ptoff;
+  DevArr<uint16_t> d_ptiles;
   DevArr<PatRec> d_pats;
   DevArr<Desc> d_dJ, d_dS;
   DevArr<int2> d_mapJ, d_mapS, d_lmapJ, d_lmapS;
@@ -162,6 +167,7 @@ struct Engine : EngineBase {
   DevArr<uint16_t> d_perm;
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
+  int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   // counters
   mmhn_counters cnt{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -196,9 +202,12 @@ struct Engine : EngineBase {
       HIPCHECK(hipMemcpy(d_lvl.p, lvl.data(), lvl.size() * sizeof(int), hipMemcpyHostToDevice));
       const char* sv = std::getenv("MMHN_SOLVER");
       use_jacobi = sv && std::string(sv) == "jacobi";
+      if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) psolve_min = std::atoi(pm);
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -338,6 +347,26 @@ struct Engine : EngineBase {
     const Desc* d; const int2* map; int ntiles; int maxk; long long vec;
     const int2* lmap; const std::vector<int>* lof; const T* tab;
   };
+
+  // joint solves with many patients in flight: one workgroup per patient, single launch (k_psolve)
+  size_t psolve_lds(int maxk) const {
+    return DESC_PAD + ((size_t)(1 << TB) + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t);
+  }
+  void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
+    const int nJ = (int)b.dJ.size();
+    if (nJ == 0) return;
+    const int mk = std::max(b.maxkJ, 1);
+    const size_t lds = psolve_lds(mk);
+    const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
+    timed(bytes, [&]() {
+      if (tr)
+        hipLaunchKernelGGL((k_psolve<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
+                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p);
+      else
+        hipLaunchKernelGGL((k_psolve<T, false>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
+                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p);
+    });
+  }
 
   // (D - Q)^-1 rhs (tr: transposed) on every problem of a list.
   //   default: tile-level substitution (k_tsolve), one launch per level of tile-index popcount;
@@ -486,9 +515,22 @@ struct Engine : EngineBase {
         HIPCHECK(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
       };
       build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
+      b.ptoff.assign(1, 0);
+      b.ptiles.clear();
+      {
+        size_t pos = 0;
+        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
+          while (pos < b.mapJ.size() && b.mapJ[pos].x == (int)pj) {
+            if (!dead_tile(b.dJ[pj], (uint32_t)b.mapJ[pos].y)) b.ptiles.push_back((uint16_t)b.mapJ[pos].y);
+            ++pos;
+          }
+          b.ptoff.push_back((int)b.ptiles.size());
+        }
+      }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
+      up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles);
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
@@ -534,7 +576,9 @@ struct Engine : EngineBase {
       if (!use_jacobi && grad && qJ_owner != b.id) { zero(qJ.p, b.vecJ); qJ_owner = b.id; }
       // 1-2 joint forward
       if (use_jacobi) launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
-      solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
+      const bool per_patient = !use_jacobi && nJ >= psolve_min;
+      if (per_patient) psolve(false, b, pi.p, 2);
+      else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
       // 3 marginal right-hand sides
       zero(rhsS.p, b.vecS);
       if (nJ) {
@@ -570,6 +614,7 @@ struct Engine : EngineBase {
             HIPCHECK(hipGetLastError());
           }
           if (use_jacobi) solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
+          else if (per_patient) psolve(true, b, qJ.p, 3);
           else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);

@@ -618,6 +618,221 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
 }
 
 // ------------------------------------------------------------------------------------
+// k_psolve: the same triangular solve, one workgroup per PATIENT.
+//
+// With hundreds of patients in flight there is no need for parallelism inside a patient: index order is itself a
+// valid substitution order (every neighbour H ^ bit of a tile has a smaller tile index; larger for the
+// transpose), so one workgroup walks its patient's live tiles in that order.  Descriptor, rate tables, pext
+// tables and the popcount permutation are set up once per patient instead of once per tile, the solve is a
+// single launch, and the neighbour tiles a tile reads were written moments earlier by the same CU.
+// Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
+// ------------------------------------------------------------------------------------
+template <typename T, bool TR>
+__global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ descs,
+                                                   const int* __restrict__ pt_off,
+                                                   const uint16_t* __restrict__ ptiles,
+                                                   const Params<T>* __restrict__ par, T* y, int rhs_mode,
+                                                   const uint16_t* __restrict__ perm, int maxk,
+                                                   const T* __restrict__ tab,
+                                                   const JLink<T>* __restrict__ links,
+                                                   const T* __restrict__ qS) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Desc& d = *reinterpret_cast<Desc*>(smem);
+  T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
+  T* Ltab = yt + (1 << TB);
+  T* Urow = Ltab + maxk * 64;
+  T* Utab = Urow + maxk * 64;
+  T* thc = Utab + maxk * 64;
+  T* hx = thc + maxk * maxk;
+  uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries + 3 per-tile high parts
+  const int tid = threadIdx.x;
+  const int prob = blockIdx.x;
+  load_desc(&d, descs + prob);
+  __syncthreads();
+  const int k = d.k;
+  const int t = k < TB ? k : TB;
+  const uint32_t nelem = 1u << t, tmask = nelem - 1;
+  const long long base = d.off;
+  constexpr int NJ = (1 << TB) / TSB;
+  constexpr int NW = TSB / 64;
+  const int wave = tid >> 6, lane = tid & 63;
+  const uint32_t last = (1u << k) - 1u;
+  // ---- once per patient: tables, pext lookups, popcount order of this thread's states
+  {
+    const T* src = tab + d.toff;
+    for (int e = tid; e < k * k; e += TSB) thc[e] = src[e];
+    for (int e = tid; e < k * 64; e += TSB) { Ltab[e] = src[k * k + e]; Urow[e] = src[k * k + k * 64 + e]; }
+  }
+  const uint32_t cP = d.maskP & tmask, cM = d.maskM & tmask, cE = d.pairP & tmask;
+  if (tid < 384) {
+    const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
+    const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
+    pxt[tid] = half == 0 ? pext32((uint32_t)v, m & 63u) : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
+  }
+  const uint16_t* pm = perm + (size_t)t * (1 << TB);
+  uint32_t px[NJ];
+  int plev[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const uint32_t idx = (uint32_t)tid + TSB * j;
+    px[j] = idx < nelem ? pm[idx] : 0u;
+    plev[j] = idx < nelem ? __popc(px[j]) : -1;
+  }
+  const T* dP = tab + d.toff + rate_table_size(k);
+  const T* dM = dP + (1ll << __popc(d.maskP));
+  const T* dE = dM + (1ll << __popc(d.maskM));
+  const uint32_t pairP = d.pairP, lone = d.lone;
+  const int seedb = d.seedbit;
+  const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
+  JLink<T> Lk;
+  if (rhs_mode == 3) Lk = links[prob];
+  __syncthreads();
+
+  for (int it = 0; it < ntile; ++it) {
+    const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
+    const uint32_t xhi = H << t;
+    // ---- per tile: tile-bit factors, compact high parts of the class indices
+    if (tid < k) {
+      T h = thc[tid * k + tid];
+      for (int bb = t; bb < k; ++bb) if (bb != tid && ((H >> (bb - t)) & 1u)) h *= thc[tid * k + bb];
+      hx[tid] = h;
+    } else if (tid >= 64 && tid < 67) {
+      const uint32_t m = tid == 64 ? d.maskP : tid == 65 ? d.maskM : d.pairP;
+      pxt[384 + tid - 64] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
+    }
+    __syncthreads();
+    for (int e = tid; e < k * 64; e += TSB) Utab[e] = Urow[e] * hx[e >> 6];
+    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
+    const bool seed_hi = (xhi >> seedb) & 1u;
+    T lid[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t xl = px[j], x = xhi | xl;
+      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
+      T v = 1;
+      if (plev[j] >= 0) {
+        if ((x >> seedb) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
+        else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
+      }
+      lid[j] = v;
+    }
+    // ---- right-hand side
+    T acc[NJ];
+    if (rhs_mode == 3) {
+      const bool can0 = Lk.soff[0] >= 0 && (seedb < t || seed_hi) && ((xhi & d.maskP & ~tmask) == (d.maskP & ~tmask));
+      const bool can1 = Lk.soff[1] >= 0 && (seedb < t || seed_hi) && ((xhi & d.maskM & ~tmask) == (d.maskM & ~tmask));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        const uint32_t x = xhi | xl;
+        T rv = 0;
+        if (xl < nelem && ((x >> seedb) & 1u)) {
+          const uint32_t lo = xl & 63u, hi6 = xl >> 6;
+          if (can0 && (xl & cP) == cP) rv += Lk.cst[0] * qS[Lk.soff[0] + (1ll << (Lk.sk[0] - 1)) + (hM | pxt[128 + lo] | pxt[192 + hi6])];
+          if (can1 && (xl & cM) == cM) rv += Lk.cst[1] * qS[Lk.soff[1] + (1ll << (Lk.sk[1] - 1)) + (hP | pxt[lo] | pxt[64 + hi6])];
+        }
+        acc[j] = rv;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        acc[j] = (xl < nelem && (xhi | xl) == 0) ? e0_scale<T>() : T(0);
+      }
+    }
+    __syncthreads();                                   // Utab complete
+    // ---- step A: transitions that cross the tile boundary
+    for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
+      const bool is_seed = d.cls[b] == CS;
+      const bool is_pair = (pairP >> b) & 1u;
+      for (int kind = 0; kind < 2; ++kind) {
+        if (kind == 1 && !is_pair) continue;
+        const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
+        const uint32_t mh = mv >> t, ml = mv & tmask;
+        if (mh == 0) continue;
+        if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;
+        const T Lb = Ltab[b * 64 + lane];
+        T nv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+          nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = wave + NW * j;
+          const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+          const uint32_t x = xhi | xl;
+          const bool ss = (x >> seedb) & 1u;
+          const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
+          bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
+          if (kind == 1) cond = cond && !ss && e0x;
+          else if (is_seed) cond = cond && e0x;
+          else cond = cond && ss;
+          const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
+          acc[j] += cond ? term : T(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+      if (xl < nelem) yt[xl] = acc[j];
+    }
+    __syncthreads();
+    // ---- step B: popcount-ordered substitution inside the tile
+    const bool fast = seedb >= t && seed_hi;
+    for (int s = 0; s <= t; ++s) {
+      const int level = TR ? t - s : s;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (plev[j] != level) continue;
+        const uint32_t xl = px[j];
+        const uint32_t lo = xl & 63u, ro = xl >> 6;
+        T z = yt[xl];
+        uint32_t todo = TR ? (~xl & tmask) : xl;
+        if (fast) {
+          while (todo) {
+            T r[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const bool on = todo != 0;
+              const int b = on ? __ffs(todo) - 1 : 0;
+              todo &= todo - 1;
+              const T v = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ (1u << b)];
+              r[u] = on ? v : T(0);
+            }
+            z += r[0] + r[1] + r[2];
+          }
+        } else {
+          const uint32_t x = xhi | xl;
+          const bool ss = (x >> seedb) & 1u;
+          const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
+          while (todo) {
+            const int b = __ffs(todo) - 1;
+            todo &= todo - 1;
+            uint32_t mv = 1u << b;
+            bool cond;
+            if (b == seedb) cond = e0x;
+            else if (ss) cond = true;
+            else if ((pairP >> b) & 1u) {
+              mv = 3u << b;
+              cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
+            } else cond = false;
+            if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
+          }
+        }
+        yt[xl] = lid[j] * z;
+      }
+      __syncthreads();
+    }
+    // ---- step C (the barrier also makes the tile visible to this workgroup's later neighbour reads)
+    for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // k_diag: diagonal quantities of one tile.
 //   KD_DQ    out = diag(Q)                           (kron_diag, kronvec.py:964-999)
 //   KD_LIDG  out = 1 / (Dobs - diag(Q))              (likelihood.py:249-250, vanilla.py:294)
