@@ -617,6 +617,14 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
   for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
 }
 
+// wave-uniform values read from LDS land in VGPRs; move them to SGPRs where registers are tight
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ long long sgpr64(long long v) {
+  const uint32_t lo = sgpr((uint32_t)v), hi = sgpr((uint32_t)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------
 // k_psolve: the same triangular solve, one workgroup per PATIENT.
 //
@@ -645,44 +653,37 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   T* thc = Utab + maxk * 64;
   T* hx = thc + maxk * maxk;
   uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries + 3 per-tile high parts
-  const int tid = threadIdx.x;
+  const int tid0 = threadIdx.x;
+  int tid = tid0;
   const int prob = blockIdx.x;
   load_desc(&d, descs + prob);
   __syncthreads();
-  const int k = d.k;
+  const int k = sgpr(d.k);
   const int t = k < TB ? k : TB;
   const uint32_t nelem = 1u << t, tmask = nelem - 1;
-  const long long base = d.off;
+  const long long base = sgpr64(d.off);
+  const long long toff = sgpr64(d.toff);
+  const uint32_t maskP = sgpr(d.maskP), maskM = sgpr(d.maskM);
   constexpr int NJ = (1 << TB) / TSB;
   constexpr int NW = TSB / 64;
-  const int wave = tid >> 6, lane = tid & 63;
-  const uint32_t last = (1u << k) - 1u;
   // ---- once per patient: tables, pext lookups, popcount order of this thread's states
   {
-    const T* src = tab + d.toff;
+    const T* src = tab + toff;
     for (int e = tid; e < k * k; e += TSB) thc[e] = src[e];
     for (int e = tid; e < k * 64; e += TSB) { Ltab[e] = src[k * k + e]; Urow[e] = src[k * k + k * 64 + e]; }
   }
-  const uint32_t cP = d.maskP & tmask, cM = d.maskM & tmask, cE = d.pairP & tmask;
+  const uint32_t pairP = sgpr(d.pairP), lone = sgpr(d.lone);
+  const int seedb = sgpr(d.seedbit);
+  const uint32_t cP = maskP & tmask, cM = maskM & tmask, cE = pairP & tmask;
   if (tid < 384) {
     const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
     const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
     pxt[tid] = half == 0 ? pext32((uint32_t)v, m & 63u) : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
   }
   const uint16_t* pm = perm + (size_t)t * (1 << TB);
-  uint32_t px[NJ];
-  int plev[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const uint32_t idx = (uint32_t)tid + TSB * j;
-    px[j] = idx < nelem ? pm[idx] : 0u;
-    plev[j] = idx < nelem ? __popc(px[j]) : -1;
-  }
-  const T* dP = tab + d.toff + rate_table_size(k);
-  const T* dM = dP + (1ll << __popc(d.maskP));
-  const T* dE = dM + (1ll << __popc(d.maskM));
-  const uint32_t pairP = d.pairP, lone = d.lone;
-  const int seedb = d.seedbit;
+  const T* dP = tab + toff + rate_table_size(k);
+  const T* dM = dP + (1ll << __popc(maskP));
+  const T* dE = dM + (1ll << __popc(maskM));
   const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
   JLink<T> Lk;
   if (rhs_mode == 3) Lk = links[prob];
@@ -691,13 +692,26 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   for (int it = 0; it < ntile; ++it) {
     const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
     const uint32_t xhi = H << t;
+    // keep nothing thread-dependent live across tiles (64 VGPRs for two workgroups per CU): everything below is
+    // re-derived from an opaque copy of the thread index
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int wave = tid >> 6, lane = tid & 63;
+    uint32_t px[NJ];
+    int plev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t idx = (uint32_t)tid + TSB * j;
+      px[j] = idx < nelem ? pm[idx] : 0u;
+      plev[j] = idx < nelem ? __popc(px[j]) : -1;
+    }
     // ---- per tile: tile-bit factors, compact high parts of the class indices
     if (tid < k) {
       T h = thc[tid * k + tid];
       for (int bb = t; bb < k; ++bb) if (bb != tid && ((H >> (bb - t)) & 1u)) h *= thc[tid * k + bb];
       hx[tid] = h;
     } else if (tid >= 64 && tid < 67) {
-      const uint32_t m = tid == 64 ? d.maskP : tid == 65 ? d.maskM : d.pairP;
+      const uint32_t m = tid == 64 ? maskP : tid == 65 ? maskM : pairP;
       pxt[384 + tid - 64] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
     }
     __syncthreads();
@@ -719,8 +733,8 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
     // ---- right-hand side
     T acc[NJ];
     if (rhs_mode == 3) {
-      const bool can0 = Lk.soff[0] >= 0 && (seedb < t || seed_hi) && ((xhi & d.maskP & ~tmask) == (d.maskP & ~tmask));
-      const bool can1 = Lk.soff[1] >= 0 && (seedb < t || seed_hi) && ((xhi & d.maskM & ~tmask) == (d.maskM & ~tmask));
+      const bool can0 = Lk.soff[0] >= 0 && (seedb < t || seed_hi) && ((xhi & maskP & ~tmask) == (maskP & ~tmask));
+      const bool can1 = Lk.soff[1] >= 0 && (seedb < t || seed_hi) && ((xhi & maskM & ~tmask) == (maskM & ~tmask));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
