@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 #include "desc.h"
 
+#ifndef MMHN_ABL
+#define MMHN_ABL 0
+#endif
 namespace mmhn {
 
 #ifndef MMHN_TB
@@ -697,14 +700,6 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
     tid = tid0;
     asm volatile("" : "+v"(tid));
     const int wave = tid >> 6, lane = tid & 63;
-    uint32_t px[NJ];
-    int plev[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t idx = (uint32_t)tid + TSB * j;
-      px[j] = idx < nelem ? pm[idx] : 0u;
-      plev[j] = idx < nelem ? __popc(px[j]) : -1;
-    }
     // ---- per tile: tile-bit factors, compact high parts of the class indices
     if (tid < k) {
       T h = thc[tid * k + tid];
@@ -716,20 +711,8 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
     }
     __syncthreads();
     for (int e = tid; e < k * 64; e += TSB) Utab[e] = Urow[e] * hx[e >> 6];
-    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
     const bool seed_hi = (xhi >> seedb) & 1u;
-    T lid[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t xl = px[j], x = xhi | xl;
-      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
-      T v = 1;
-      if (plev[j] >= 0) {
-        if ((x >> seedb) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
-        else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
-      }
-      lid[j] = v;
-    }
+    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
     // ---- right-hand side
     T acc[NJ];
     if (rhs_mode == 3) {
@@ -755,47 +738,90 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
       }
     }
     __syncthreads();                                   // Utab complete
+    const bool fast = t == TB && seedb >= t && seed_hi;
     // ---- step A: transitions that cross the tile boundary
-    for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
-      const bool is_seed = d.cls[b] == CS;
-      const bool is_pair = (pairP >> b) & 1u;
-      for (int kind = 0; kind < 2; ++kind) {
-        if (kind == 1 && !is_pair) continue;
-        const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
-        const uint32_t mh = mv >> t, ml = mv & tmask;
-        if (mh == 0) continue;
-        if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;
+#if MMHN_ABL != 1
+    // one move (bit b; kind 1 = the pair move of P bit b) with every condition evaluated per state
+    auto gen_move = [&](int b, int kind) {
+      const bool is_seed = b == seedb;
+      const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
+      const uint32_t mh = mv >> t, ml = mv & tmask;
+      if (mh == 0) return;
+      if (TR ? (H & mh) != 0 : (H & mh) != mh) return;
+      const T Lb = Ltab[b * 64 + lane];
+      T nv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave + NW * j;
+        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+        const uint32_t x = xhi | xl;
+        const bool ss = (x >> seedb) & 1u;
+        const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
+        bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
+        if (kind == 1) cond = cond && !ss && e0x;
+        else if (is_seed) cond = cond && e0x;
+        else cond = cond && ss;
+        const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
+        acc[j] += cond ? term : T(0);
+      }
+    };
+    if (fast) {
+      // seeded full tile: pair moves never apply and a single-bit move above the tile applies to every state;
+      // the move list is a scalar bit set of the tile index
+      uint32_t mb = (TR ? ~H : H) & ((1u << (k - t)) - 1u) & ~(1u << (seedb - t));
+      while (mb) {
+        const int b = t + __ffs(mb) - 1;
+        mb &= mb - 1;
         const T Lb = Ltab[b * 64 + lane];
-        T nv[NJ];
+        const T* yn = y + base + (xhi ^ (1u << b));
+        T nf[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-          nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
-        }
+        for (int j = 0; j < NJ; ++j) nf[j] = yn[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int r = wave + NW * j;
-          const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-          const uint32_t x = xhi | xl;
-          const bool ss = (x >> seedb) & 1u;
-          const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
-          bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
-          if (kind == 1) cond = cond && !ss && e0x;
-          else if (is_seed) cond = cond && e0x;
-          else cond = cond && ss;
-          const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
-          acc[j] += cond ? term : T(0);
-        }
+        for (int j = 0; j < NJ; ++j) acc[j] += Lb * Utab[b * 64 + wave + NW * j] * nf[j];
+      }
+      if (!TR) gen_move(seedb, 0);
+    } else {
+      for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
+        gen_move(b, 0);
+        if ((pairP >> b) & 1u) gen_move(b, 1);
       }
     }
+#endif
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
       if (xl < nelem) yt[xl] = acc[j];
     }
+    // popcount order of this thread's states and their inverse diagonals (after step A: registers are tight)
+    uint32_t px[NJ];
+    int plev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t idx = (uint32_t)tid + TSB * j;
+      px[j] = idx < nelem ? pm[idx] : 0u;
+      plev[j] = idx < nelem ? __popc(px[j]) : -1;
+    }
+    T lid[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const uint32_t xl = px[j], x = xhi | xl;
+      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
+      T v = 1;
+      if (plev[j] >= 0) {
+        if ((x >> seedb) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
+        else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
+      }
+      lid[j] = v;
+    }
     __syncthreads();
     // ---- step B: popcount-ordered substitution inside the tile
-    const bool fast = seedb >= t && seed_hi;
+#if MMHN_ABL != 2
     for (int s = 0; s <= t; ++s) {
       const int level = TR ? t - s : s;
 #pragma unroll
@@ -840,6 +866,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
       }
       __syncthreads();
     }
+#endif
     // ---- step C (the barrier also makes the tile visible to this workgroup's later neighbour reads)
     for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
     __syncthreads();
