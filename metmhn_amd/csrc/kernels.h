@@ -620,6 +620,20 @@ __global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ desc
   for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
 }
 
+// 1 / v for a positive, normal-range v (sums of rates): hardware reciprocal + two Newton steps (full precision
+// for fp64, no scaling / fix-up sequence of the IEEE division)
+__device__ __forceinline__ double fast_rcp(double v) {
+  double r = __builtin_amdgcn_rcp(v);
+  r = fma(fma(-v, r, 1.0), r, r);
+  r = fma(fma(-v, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float v) {
+  float r = __builtin_amdgcn_rcpf(v);
+  r = fmaf(fmaf(-v, r, 1.0f), r, r);
+  return r;
+}
+
 // wave-uniform values read from LDS land in VGPRs; move them to SGPRs where registers are tight
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -650,7 +664,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
-  T* Ltab = yt + (1 << TB);
+  T* Ltab = yt + (1 << TB) + 2;                                 // yt[1 << TB] stays 0: target of padded reads
   T* Urow = Ltab + maxk * 64;
   T* Utab = Urow + maxk * 64;
   T* thc = Utab + maxk * 64;
@@ -678,6 +692,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   const uint32_t pairP = sgpr(d.pairP), lone = sgpr(d.lone);
   const int seedb = sgpr(d.seedbit);
   const uint32_t cP = maskP & tmask, cM = maskM & tmask, cE = pairP & tmask;
+  if (tid == 0) yt[1 << TB] = T(0);
   if (tid < 384) {
     const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
     const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
@@ -814,7 +829,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
       const uint32_t lo = xl & 63u, hi6 = xl >> 6;
       T v = 1;
       if (plev[j] >= 0) {
-        if ((x >> seedb) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
+        if ((x >> seedb) & 1u) v = fast_rcp(dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
         else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
       }
       lid[j] = v;
@@ -839,8 +854,8 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
               const bool on = todo != 0;
               const int b = on ? __ffs(todo) - 1 : 0;
               todo &= todo - 1;
-              const T v = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ (1u << b)];
-              r[u] = on ? v : T(0);
+              const uint32_t yi = on ? (xl ^ (1u << b)) : (1u << TB);      // padded slot reads the zero
+              r[u] = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[yi];
             }
             z += r[0] + r[1] + r[2];
           }
