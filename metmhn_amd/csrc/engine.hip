@@ -87,6 +87,7 @@ struct Batch {
   std::vector<int2> lmapJ, lmapS;
   std::vector<int> lofJ, lofS;
   // live tiles of every joint problem in index order (k_psolve: one workgroup per patient)
+  bool class_ok = true;          // every joint problem has at most PCA + PCH bits per class (k_pclass)
   std::vector<int> ptoff;
   std::vector<uint16_t> ptiles;
   DevArr<int> d_ptoff;
@@ -220,6 +221,7 @@ struct Engine : EngineBase {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_rows<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_class_marg<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
@@ -517,6 +519,9 @@ struct Engine : EngineBase {
       build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
       b.ptoff.assign(1, 0);
       b.ptiles.clear();
+      b.class_ok = true;
+      for (const Desc& dj : b.dJ)
+        if (popc(dj.maskP) > PCA + PCH || popc(dj.maskM) > PCA + PCH) b.class_ok = false;
       {
         size_t pos = 0;
         for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
@@ -618,8 +623,12 @@ struct Engine : EngineBase {
           else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);
-          hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(CMB), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
-                             b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
+          if (per_patient && b.class_ok)
+            hipLaunchKernelGGL((k_pclass<T>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
+                               pi.p, qJ.p, Abuf.p);
+          else
+            hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(CMB), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
+                               b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());

@@ -1311,6 +1311,160 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   }
 }
 
+// ------------------------------------------------------------------------------------
+// k_pclass: the class marginals of k_class_marg, one workgroup per PATIENT, accumulated in registers.
+//
+// For class c the joint vectors are viewed as matrices p[S][F], q[S][F] (S = setting of the class-c bits, F =
+// setting of the other class's bits, seeding = 1).  The outputs are row dot products,
+//   W[S] = -sum_F p[S][F] q[S][F],      V_b[S] = sum_F p[S][F] q[S | b][F]   (b a class bit clear in S),
+// so a tile here is NOT the low TB index bits: it holds the lowest a = min(kc, PCA) class bits (all of them when
+// kc <= PCA) and is filled up to TB bits with the lowest other-class bits.  Every in-tile slot's neighbour is
+// then in LDS at a constant offset, the sum over the remaining F bits runs over the patient's tiles with the
+// accumulators in registers, and each output is written once per patient (no per-tile atomics, no cross-lane
+// reductions).  Tiles are staged in the permuted order e' = S + RS * F (RS = 2^a + pad), gathered from HBM in
+// memory order (contiguous runs of >= 128 B whenever the four lowest index bits are tile bits).
+// Class bits above the a-th (kc > PCA) make an outer loop over blocks Shi; their slots take a second pass per
+// tile with the neighbour block's q staged over qt.  Per class pass p and q are read once (+ the neighbour
+// blocks), i.e. about 4 vector-halves per patient against 2 + the high-slot rows of k_class_marg.
+// ------------------------------------------------------------------------------------
+constexpr int PCA = 10;                            // class bits inside a tile (two accumulator sets per wave)
+constexpr int PCH = 5;                             // class bits above the tile (kc <= PCA + PCH)
+constexpr int PC_PAD = 4;                          // row pad (elements) of the staged layout: conflict-free ds_write_b64
+constexpr int PC_LDS_ELEMS = 2 * ((1 << TB) + PC_PAD * 64) + (1 << (PCA - 1));
+
+__device__ __forceinline__ uint32_t low_bits(uint32_t m, int n) {
+  uint32_t r = 0;
+  for (int i = 0; i < n && m; ++i) { r |= m & (0u - m); m &= m - 1; }
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, const T* __restrict__ p,
+                                                   const T* __restrict__ q, T* A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* pt = reinterpret_cast<T*>(smem);
+  T* qt = pt + (1 << TB) + PC_PAD * 64;                  // + 2^(PCA-1) slack behind it for the neighbour reads
+  const Desc& d = dJ[blockIdx.x];
+  const int seedbit = d.seedbit;
+  if (seedbit < 0) return;
+  const int k = d.k;
+  const uint32_t sbm = 1u << seedbit;
+  const uint32_t allbits = (k >= 32 ? 0xffffffffu : ((1u << k) - 1u)) & ~sbm;
+  const uint32_t maskP = d.maskP, maskM = d.maskM;
+  const long long off = d.off;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NWV = CMB / 64;                           // 8 waves: rows w, w + 8, ... of a tile
+  constexpr int NST = (1 << TB) / CMB;
+  constexpr int NROW = (1 << TB) / 64 / NWV;              // rows per wave of a full tile
+  const int kP = __popc(maskP);
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t cmask = c == 0 ? maskP : maskM;
+    const uint32_t other = allbits & ~cmask;
+    const int kc = __popc(cmask), kf = __popc(other);
+    const int a = kc < PCA ? kc : PCA;
+    const int nfl = kf < TB - a ? kf : TB - a;
+    const int t2 = a + nfl, nh = kc - a, no = kf - nfl;
+    const uint32_t nelem2 = 1u << t2;
+    const uint32_t clow = low_bits(cmask, a), chigh = cmask & ~clow;
+    const uint32_t fill = low_bits(other, nfl), omask = other & ~fill;
+    const uint32_t tilemask = clow | fill;
+    const uint32_t mA = (1u << a) - 1u;
+    const uint32_t RS = (1u << a) + (a >= 6 ? PC_PAD : 0);
+    T* out = A + d.aoff + (c == 0 ? 0 : class_block_size(kP));
+    // staging map of this thread: memory-order element m of the tile -> offset in the vector, slot in LDS
+    uint32_t goff[NST], eo[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const uint32_t m = (uint32_t)tid + CMB * u;
+      const uint32_t g = pdep32(m, tilemask);
+      goff[u] = g;
+      eo[u] = m < nelem2 ? pext32(g, clow) + RS * pext32(g, fill) : 0xffffffffu;
+    }
+    __syncthreads();                                      // previous class done with the staged tile
+    for (int e = tid; e < PC_LDS_ELEMS; e += CMB) pt[e] = T(0);
+    const uint32_t nrows1 = nelem2 > 64 ? nelem2 >> 6 : 1;   // rows of 64 states (a small tile is one partial row)
+    for (uint32_t Shi = 0; Shi < (1u << nh); ++Shi) {
+      T acc[2][PCA + 1], acch[2][PCH];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j <= PCA; ++j) acc[s][j] = T(0);
+#pragma unroll
+        for (int j = 0; j < PCH; ++j) acch[s][j] = T(0);
+      }
+      const uint32_t cbase = pdep32(Shi, chigh);
+      for (uint32_t o = 0; o < (1u << no); ++o) {
+        const uint32_t obase = sbm | pdep32(o, omask);
+        {
+          const long long base = off + (long long)(obase | cbase);
+          T rp[NST], rq[NST];
+#pragma unroll
+          for (int u = 0; u < NST; ++u) {
+            const bool ok = eo[u] != 0xffffffffu;
+            rp[u] = ok ? p[base + goff[u]] : T(0);
+            rq[u] = ok ? q[base + goff[u]] : T(0);
+          }
+          __syncthreads();                                // previous tile reduced
+#pragma unroll
+          for (int u = 0; u < NST; ++u)
+            if (eo[u] != 0xffffffffu) { pt[eo[u]] = rp[u]; qt[eo[u]] = rq[u]; }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NROW; ++i) {
+          const uint32_t r = (uint32_t)w + NWV * i;
+          if (r >= nrows1) break;
+          const uint32_t e = (r << 6) | (uint32_t)lane;
+          const uint32_t ea = (e & mA) + RS * (e >> a);
+          const T pv = pt[ea];
+          acc[i & 1][0] += pv * qt[ea];
+#pragma unroll
+          for (int j = 0; j < PCA; ++j)
+            if (j < a) acc[i & 1][1 + j] += pv * qt[ea + (1u << j)];
+        }
+        // slots of the class bits above the tile: the neighbour block's q replaces qt for one pass each
+#pragma unroll
+        for (int hb = 0; hb < PCH; ++hb) {
+          if (hb >= nh || ((Shi >> hb) & 1u)) continue;
+          const long long nb = off + (long long)(obase | pdep32(Shi | (1u << hb), chigh));
+          T rq[NST];
+#pragma unroll
+          for (int u = 0; u < NST; ++u) rq[u] = eo[u] != 0xffffffffu ? q[nb + goff[u]] : T(0);
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < NST; ++u)
+            if (eo[u] != 0xffffffffu) qt[eo[u]] = rq[u];
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < NROW; ++i) {
+            const uint32_t r = (uint32_t)w + NWV * i;
+            if (r >= nrows1) break;
+            const uint32_t e = (r << 6) | (uint32_t)lane;
+            const uint32_t ea = (e & mA) + RS * (e >> a);
+            acch[i & 1][hb] += pt[ea] * qt[ea];
+          }
+        }
+      }
+      // ---- flush this block's rows of the class-marginal tables
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t Sl = ((((uint32_t)w + NWV * s) << 6) | (uint32_t)lane) & mA;
+        const long long S = ((long long)Shi << a) | Sl;
+        if (acc[s][0] != T(0)) atomicAdd(&out[S], -acc[s][0]);
+#pragma unroll
+        for (int j = 0; j < PCA; ++j)
+          if (j < a && !((Sl >> j) & 1u) && acc[s][1 + j] != T(0))
+            atomicAdd(&out[((long long)(1 + j) << kc) + S], acc[s][1 + j]);
+#pragma unroll
+        for (int hb = 0; hb < PCH; ++hb)
+          if (hb < nh && !((Shi >> hb) & 1u) && acch[s][hb] != T(0))
+            atomicAdd(&out[((long long)(1 + a + hb) << kc) + S], acch[s][hb]);
+      }
+    }
+  }
+}
+
 // eq block (seed = 0 states with PT == MT): subsets e of the paired events, x0 = both bits
 //   slot 0      -p[x0] q[x0]
 //   slot 1 + l   p[x0] q[x0 | pair_l]          (pair_l not in e)
