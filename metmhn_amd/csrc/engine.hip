@@ -87,7 +87,10 @@ struct Batch {
   std::vector<int2> lmapJ, lmapS;
   std::vector<int> lofJ, lofS;
   // live tiles of every joint problem in index order (k_psolve: one workgroup per patient)
-  bool class_ok = true;          // every joint problem has at most PCA + PCH bits per class (k_pclass)
+  // tiles of the joint problems with more than PCA + PCH bits in one class: k_pclass skips them, k_class_marg
+  // takes them
+  std::vector<int2> mapX;
+  DevArr<int2> d_mapX;
   std::vector<int> ptoff;
   std::vector<uint16_t> ptiles;
   DevArr<int> d_ptoff;
@@ -519,9 +522,11 @@ struct Engine : EngineBase {
       build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
       b.ptoff.assign(1, 0);
       b.ptiles.clear();
-      b.class_ok = true;
-      for (const Desc& dj : b.dJ)
-        if (popc(dj.maskP) > PCA + PCH || popc(dj.maskM) > PCA + PCH) b.class_ok = false;
+      b.mapX.clear();
+      for (const int2& m : b.mapJ) {
+        const Desc& dj = b.dJ[m.x];
+        if (popc(dj.maskP) > PCA + PCH || popc(dj.maskM) > PCA + PCH) b.mapX.push_back(m);
+      }
       {
         size_t pos = 0;
         for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
@@ -535,7 +540,7 @@ struct Engine : EngineBase {
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
-      up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles);
+      up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles); up(b.d_mapX, b.mapX);
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
@@ -623,12 +628,16 @@ struct Engine : EngineBase {
           else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
           // 6 joint gradient
           zero(Abuf.p, b.asize);
-          if (per_patient && b.class_ok)
+          if (per_patient) {
             hipLaunchKernelGGL((k_pclass<T>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
                                pi.p, qJ.p, Abuf.p);
-          else
+            if (!b.mapX.empty())
+              hipLaunchKernelGGL((k_class_marg<T>), dim3((unsigned)b.mapX.size()), dim3(CMB), 2 * sizeof(T) << TB, stream,
+                                 b.d_dJ.p, b.d_mapX.p, pi.p, qJ.p, Abuf.p);
+          } else {
             hipLaunchKernelGGL((k_class_marg<T>), dim3(tJ), dim3(CMB), 2 * sizeof(T) << TB, stream, b.d_dJ.p,
                                b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
+          }
           HIPCHECK(hipGetLastError());
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());

@@ -1351,6 +1351,7 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   const uint32_t sbm = 1u << seedbit;
   const uint32_t allbits = (k >= 32 ? 0xffffffffu : ((1u << k) - 1u)) & ~sbm;
   const uint32_t maskP = d.maskP, maskM = d.maskM;
+  if (__popc(maskP) > PCA + PCH || __popc(maskM) > PCA + PCH) return;     // left to k_class_marg
   const long long off = d.off;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -350,6 +350,44 @@ def test_awkward_layouts_substitution_vs_jacobi(monkeypatch):
     np.testing.assert_allclose(a[3][6], gm, rtol=1e-8, atol=1e-10)
 
 
+def test_per_patient_kernels_match_tile_kernels(monkeypatch):
+    """One-workgroup-per-patient kernels (k_psolve, k_pclass: class-aligned tiles, register accumulators, class
+    bits above the tile, > 15 class bits left to k_class_marg) against the per-tile kernels on k = 14..20
+    spaces with skewed PT / MT splits, and against the C oracle on a k = 15 space with 12 PT bits."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 20
+    lt, dp, dm = synthetic.random_params(n, seed=11)
+    rows = [
+        _row(n, range(3), range(4, 20), 0),                     # kP = 3, kM = 16: class marginals fall back
+        _row(n, range(16), [17, 18, 19], 1),                    # kP = 16
+        _row(n, range(13), range(10, 16), 2),                   # kP = 13, kM = 6, three pairs
+        _row(n, list(range(0, 20, 2)) + [1], range(1, 17, 2), 0),   # kP = 11, kM = 8
+        _row(n, range(10), range(5, 14), 1),                    # kP = 10, kM = 9
+        _row(n, [0, 19], range(6, 19), 2),                      # kP = 2, kM = 13
+        _row(n, range(12), [12, 13], 0),                        # k = 15, kP = 12 (two class bits above the tile)
+        _row(n, [], range(14), -99),                            # k = 15, MT only
+        _row(n, range(7), range(7), 1),                         # k = 15, all paired
+    ]
+    dat = np.array(rows, dtype=np.int8)
+    res = []
+    for pmin in ("1", "1000000"):
+        monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+        e = Engine(n)
+        e.set_cohort(dat)
+        res.append(e.patient_grads(lt, dp, dm))
+        e.close()
+    for x, y in zip(*res):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+    cref.load()
+    lp, g, gp, gm = cref.patients(lt, dp, dm, dat[6:7], with_grad=True)
+    a = res[0]
+    np.testing.assert_allclose(a[0][6], lp[0], rtol=1e-10)
+    np.testing.assert_allclose(a[1][6], g[0], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[2][6], gp[0], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a[3][6], gm[0], rtol=1e-8, atol=1e-10)
+
+
 def test_per_patient_reference_entry_points(golden):
     """ssr._g_coupled_* / _lp_* / _grad_*_obs and mhn.gradient mirrors (reference argument orders)."""
     from metmhn_amd.jx import likelihood as L, vanilla as V
