@@ -82,6 +82,7 @@ struct Batch {
   long long vecJ = 0, vecS = 0, asize = 0, tabJ = 0, tabS = 0;
   int id = 0;
   int maxkJ = 0, maxkS = 0;
+  int maxkcJ = 0;                // most bits of one class (PT / MT) over the joint problems
   bool has_kind2 = false;
   // tiles sorted by level = popcount(tile index) for the substitution solver; lof* = level offsets
   std::vector<int2> lmapJ, lmapS;
@@ -322,7 +323,9 @@ struct Engine : EngineBase {
     const int maxhi = std::max(0, maxk - 6);
     const size_t lds = ((size_t)WAVES * 64 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
-    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream, descs,
+    // partial rows of the subset chunks are added up: G (and dj) must be zero on entry
+    const int nchunk = 1 << std::max(0, maxk - GR_CHUNK);
+    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (rows + WAVES - 1) / WAVES, nchunk), dim3(BLOCK), lds, stream, descs,
                        d_par.p, A, p, q, G, kind, maxhi, dj);
     HIPCHECK(hipGetLastError());
   }
@@ -486,6 +489,7 @@ struct Engine : EngineBase {
         pr.j = (int)cur.dJ.size();
         add_tiles(cur.mapJ, pr.j, dj.k);
         cur.maxkJ = std::max(cur.maxkJ, dj.k);
+        cur.maxkcJ = std::max(cur.maxkcJ, std::max(popc(dj.maskP), popc(dj.maskM)));
         cur.dJ.push_back(dj);
       }
       if (has0) {
@@ -605,6 +609,7 @@ struct Engine : EngineBase {
       HIPCHECK(hipGetLastError());
       if (grad) {
         solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
+        zero(GS.p, (long long)nS * N * N);
         launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S);
         if (b.has_kind2) {
           zero(bmS.p, (long long)nS * 64);
@@ -642,8 +647,10 @@ struct Engine : EngineBase {
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           const long long gjs = (long long)nJ * N * N;
+          zero(GJ.p, 3 * gjs);
+          zero(DJ.p, 3ll * nJ * N);
           for (int kd = 0; kd < 3; ++kd)
-            launch_grad_rows(b.d_dJ.p, nJ, b.maxkJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, DJ.p);
+            launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, DJ.p);
         }
         // 7 assembly
       }
@@ -763,6 +770,7 @@ struct Engine : EngineBase {
     up(m.b, x, V);   // q (left vector)
     m.c.alloc((size_t)a_size(m.d));
     m.e.alloc((size_t)3 * N * N);
+    zero(m.e.p, 3ll * N * N);
     zero(m.c.p, a_size(m.d));
     hipLaunchKernelGGL((k_class_marg<T>), dim3(m.ntiles), dim3(CMB), 2 * sizeof(T) << TB, stream, m.dd.p, m.map.p,
                        m.a.p, m.b.p, m.c.p);
@@ -780,6 +788,7 @@ struct Engine : EngineBase {
     up(m.a, y, V);
     up(m.b, x, V);
     m.e.alloc((size_t)N * N);
+    zero(m.e.p, (long long)N * N);
     launch_grad_rows(m.dd.p, 1, d0.k, nullptr, m.a.p, m.b.p, m.e.p, GK_S);
     down(G, m.e.p, (size_t)N * N);
     if (ddiag)

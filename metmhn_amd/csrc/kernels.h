@@ -94,7 +94,8 @@ __host__ __device__ inline long long table_size(const Desc& d) {
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
                                                 const Params<T>* __restrict__ par, T* tab) {
-  __shared__ T thc[MAXN * MAXN];        // later reused as th[i][class bit l]
+  __shared__ T thc[(MAXN + 1) * MAXN];  // later reused as th[i][class bit l]
+  __shared__ T rsplit[(MAXN + 1) * 192];  // [i][three 6-bit parts of S] partial rate products (row N: observation)
   __shared__ Desc d;
   load_desc(&d, descs + blockIdx.x);
   __syncthreads();
@@ -138,10 +139,33 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     }
     __syncthreads();
     const T* dv = c == 1 ? P.dm : P.dp;
-    for (long long S = tid; S < (1ll << kc); S += BLOCK) {
-      T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
+    // row N of the table: the observation factors dvec[event of bit l]
+    for (int l = tid; l < kc; l += BLOCK) {
       uint32_t m = cm;
-      for (int l = 0; l < kc; ++l) { const int b = __ffs(m) - 1; m &= m - 1; if ((S >> l) & 1) obs *= dv[d.ev[b]]; }
+      for (int q = 0; q < l; ++q) m &= m - 1;
+      thc[N * kc + l] = dv[d.ev[__ffs(m) - 1]];
+    }
+    __syncthreads();
+    // prod_{l in S} th[i][l] split over three 6-bit parts of S: three table reads per (i, S) instead of kc
+    // conditional multiplies (kc <= 18; longer lattices keep the loop)
+    const bool split = kc <= 18;
+    if (split) {
+      for (int e = tid; e < (N + 1) * 192; e += BLOCK) {
+        const int i = e / 192, part = (e % 192) >> 6, v = e & 63;
+        T r = 1;
+        for (int l = 0; l < 6; ++l) {
+          const int ll = part * 6 + l;
+          if (ll < kc && ((v >> l) & 1)) r *= thc[i * kc + ll];
+        }
+        rsplit[e] = r;
+      }
+      __syncthreads();
+    }
+    for (long long S = tid; S < (1ll << kc); S += BLOCK) {
+      const int s0 = (int)(S & 63), s1 = (int)((S >> 6) & 63), s2 = (int)(S >> 12);
+      T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
+      if (split) obs *= rsplit[N * 192 + s0] * rsplit[N * 192 + 64 + s1] * rsplit[N * 192 + 128 + s2];
+      else for (int l = 0; l < kc; ++l) if ((S >> l) & 1) obs *= thc[N * kc + l];
       T tot = obs;
       const int rows = c == 2 ? N : n;          // the eq block also carries the seeding rate (row n)
       for (int i = 0; i < rows; ++i) {
@@ -152,7 +176,8 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
           if ((S >> l) & 1) continue;
         }
         T r = c == 1 ? P.baseM[i] : P.baseP[i];
-        for (int l = 0; l < kc; ++l) if ((S >> l) & 1) r *= thc[i * kc + l];
+        if (split) r *= rsplit[i * 192 + s0] * rsplit[i * 192 + 64 + s1] * rsplit[i * 192 + 128 + s2];
+        else for (int l = 0; l < kc; ++l) if ((S >> l) & 1) r *= thc[i * kc + l];
         tot += r;
       }
       o[S] = tot;
@@ -1517,6 +1542,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 // grid = (problems, ceil(N / WAVES)); wave w of a workgroup owns event i = blockIdx.y * WAVES + w
 // and strides the subsets S across its lanes; all reductions are wave-level.
+constexpr int GR_CHUNK = 13;                      // subsets per workgroup of k_grad_rows: 2^13
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ descs,
                                                      const Params<T>* __restrict__ par,
@@ -1550,6 +1577,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
   //    GK_E -> d_dp on the seed = 0 states, where D_m = 0)
   const bool drow = i == N;
   if (i > N || (drow && (kind == GK_S || DJ == nullptr))) return;
+  if (((long long)blockIdx.z << GR_CHUNK) >= (1ll << kc)) return;          // chunk beyond this problem's lattice
   T* row = drow ? DJ + ((long long)kind * gridDim.x + blockIdx.x) * N : G + ((long long)blockIdx.x * N + i) * N;
   T* rb = rowbuf + w * 32;
   if (lane < 32) rb[lane] = 0;
@@ -1582,28 +1610,43 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       Ab = A + o;
     }
     const long long nS = 1ll << kc;
+    // workgroup z takes the subsets [z, z + 1) << GR_CHUNK (long lattices are split, partial rows are added up)
+    const long long Sbeg = (long long)blockIdx.z << GR_CHUNK;
+    const long long Send = nS < Sbeg + (1ll << GR_CHUNK) ? nS : Sbeg + (1ll << GR_CHUNK);
     T tot = 0;
-    for (long long S0 = 0; S0 < nS; S0 += 64) {
-      const long long S = S0 + lane;
-      const uint32_t s = (uint32_t)S;
-      T urate = base;                            // wave-uniform part of the rate
-      for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
-      T f = 0;
-      const bool blocked = slot >= 0 && slot < kc && ((s >> slot) & 1u);
-      if (S < nS && !blocked) {
-        T a0, a1 = 0;
-        if (kind == GK_S) {
-          const T pv = p[d.off + s];
-          a0 = -pv * q[d.off + s];
-          if (slot >= 0) a1 = pv * q[d.off + (s | (1u << slot))];
-        } else {
-          a0 = Ab[S];
-          if (slot >= 0) a1 = Ab[((long long)(slot + 1) << kc) + S];
+    constexpr int GU = 4;                          // chunks of 64 subsets in flight per wave
+    for (long long S00 = Sbeg; S00 < Send; S00 += 64 * GU) {
+      T a0[GU], a1[GU];
+      bool live[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const long long S = S00 + 64 * u + lane;
+        const uint32_t s = (uint32_t)S;
+        const bool blocked = slot >= 0 && slot < kc && ((s >> slot) & 1u);
+        live[u] = S < nS && !blocked;
+        a0[u] = 0; a1[u] = 0;
+        if (live[u]) {
+          if (kind == GK_S) {
+            const T pv = p[d.off + s];
+            a0[u] = -pv * q[d.off + s];
+            if (slot >= 0) a1[u] = pv * q[d.off + (s | (1u << slot))];
+          } else {
+            a0[u] = Ab[S];
+            if (slot >= 0) a1[u] = Ab[((long long)(slot + 1) << kc) + S];
+          }
         }
-        f = urate * Tlo[w * 64 + (s & 63u)] * (a0 + a1);
       }
-      tot += f;
-      for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const long long S0 = S00 + 64 * u;
+        if (S0 >= nS) break;
+        const uint32_t s = (uint32_t)(S0 + lane);
+        T urate = base;                            // wave-uniform part of the rate
+        for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
+        const T f = live[u] ? urate * Tlo[w * 64 + (s & 63u)] * (a0[u] + a1[u]) : T(0);
+        tot += f;
+        for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
+      }
     }
     const T total = wave_sum(tot);
     if (lane == 0) {
@@ -1616,7 +1659,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
     }
   }
-  if (lane < N) row[lane] = rb[lane];
+  if (lane < N && rb[lane] != T(0)) atomicAdd(&row[lane], rb[lane]);
 }
 
 // ------------------------------------------------------------------------------------
