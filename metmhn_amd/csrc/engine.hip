@@ -92,6 +92,7 @@ struct Batch {
   // takes them
   std::vector<int2> mapX;
   DevArr<int2> d_mapX;
+  DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
   std::vector<int> ptoff;
   std::vector<uint16_t> ptiles;
   DevArr<int> d_ptoff;
@@ -317,16 +318,26 @@ struct Engine : EngineBase {
     HIPCHECK(hipGetLastError());
   }
   // dj != nullptr (joint kinds): one extra row per problem with the observation-rate gradient
+  // work list of k_grad_rows: one entry per (problem, chunk of 2^GR_CHUNK subsets of the kind's lattice)
+  static std::vector<int2> grad_chunks(const std::vector<Desc>& ds, int kind) {
+    std::vector<int2> out;
+    for (size_t i = 0; i < ds.size(); ++i) {
+      const Desc& d = ds[i];
+      const int kc = kind == GK_P ? popc(d.maskP) : kind == GK_M ? popc(d.maskM) : kind == GK_E ? popc(d.pairP) : d.k;
+      const int nch = 1 << std::max(0, kc - GR_CHUNK);
+      for (int c = 0; c < nch; ++c) out.push_back(int2{(int)i, c});
+    }
+    return out;
+  }
+  // partial rows of the subset chunks are added up: G (and dj) must be zero on entry
   void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind,
-                        T* dj = nullptr) {
-    if (nprob == 0) return;
+                        const DevArr<int2>& chunks, T* dj = nullptr) {
+    if (nprob == 0 || chunks.n == 0) return;
     const int maxhi = std::max(0, maxk - 6);
     const size_t lds = ((size_t)WAVES * 64 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
-    // partial rows of the subset chunks are added up: G (and dj) must be zero on entry
-    const int nchunk = 1 << std::max(0, maxk - GR_CHUNK);
-    hipLaunchKernelGGL((k_grad_rows<T>), dim3(nprob, (rows + WAVES - 1) / WAVES, nchunk), dim3(BLOCK), lds, stream, descs,
-                       d_par.p, A, p, q, G, kind, maxhi, dj);
+    hipLaunchKernelGGL((k_grad_rows<T>), dim3((unsigned)chunks.n, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream,
+                       descs, d_par.p, A, p, q, G, kind, maxhi, dj, chunks.p, nprob);
     HIPCHECK(hipGetLastError());
   }
   void zero(T* p, long long count) {
@@ -545,6 +556,10 @@ struct Engine : EngineBase {
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles); up(b.d_mapX, b.mapX);
+      for (int kd = 0; kd < 4; ++kd) {
+        std::vector<int2> gc = grad_chunks(kd == GK_S ? b.dS : b.dJ, kd);
+        up(b.d_grc[kd], gc);
+      }
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
@@ -610,7 +625,7 @@ struct Engine : EngineBase {
       if (grad) {
         solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
         zero(GS.p, (long long)nS * N * N);
-        launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S);
+        launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grc[GK_S]);
         if (b.has_kind2) {
           zero(bmS.p, (long long)nS * 64);
           hipLaunchKernelGGL((k_bit_marg<T>), dim3(tS), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapS.p, d_par.p,
@@ -650,7 +665,7 @@ struct Engine : EngineBase {
           zero(GJ.p, 3 * gjs);
           zero(DJ.p, 3ll * nJ * N);
           for (int kd = 0; kd < 3; ++kd)
-            launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, DJ.p);
+            launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, b.d_grc[kd], DJ.p);
         }
         // 7 assembly
       }
@@ -777,7 +792,13 @@ struct Engine : EngineBase {
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());
-    for (int kd = 0; kd < 3; ++kd) launch_grad_rows(m.dd.p, 1, d0.k, m.c.p, nullptr, nullptr, m.e.p + kd * N * N, kd);
+    for (int kd = 0; kd < 3; ++kd) {
+      std::vector<int2> gc = grad_chunks(std::vector<Desc>{m.d}, kd);
+      DevArr<int2> dgc; dgc.alloc(gc.size());
+      HIPCHECK(hipMemcpy(dgc.p, gc.data(), gc.size() * sizeof(int2), hipMemcpyHostToDevice));
+      launch_grad_rows(m.dd.p, 1, d0.k, m.c.p, nullptr, nullptr, m.e.p + kd * N * N, kd, dgc);
+      HIPCHECK(hipStreamSynchronize(stream));
+    }
     std::vector<double> g(3 * N * N);
     down(g.data(), m.e.p, g.size());
     for (int e = 0; e < N * N; ++e) G[e] = g[e] + g[N * N + e] + g[2 * N * N + e];
@@ -789,7 +810,13 @@ struct Engine : EngineBase {
     up(m.b, x, V);
     m.e.alloc((size_t)N * N);
     zero(m.e.p, (long long)N * N);
-    launch_grad_rows(m.dd.p, 1, d0.k, nullptr, m.a.p, m.b.p, m.e.p, GK_S);
+    {
+      std::vector<int2> gc = grad_chunks(std::vector<Desc>{m.d}, GK_S);
+      DevArr<int2> dgc; dgc.alloc(gc.size());
+      HIPCHECK(hipMemcpy(dgc.p, gc.data(), gc.size() * sizeof(int2), hipMemcpyHostToDevice));
+      launch_grad_rows(m.dd.p, 1, d0.k, nullptr, m.a.p, m.b.p, m.e.p, GK_S, dgc);
+      HIPCHECK(hipStreamSynchronize(stream));
+    }
     down(G, m.e.p, (size_t)N * N);
     if (ddiag)
       for (int j = 0; j < N; ++j) {

@@ -1540,7 +1540,7 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
-// grid = (problems, ceil(N / WAVES)); wave w of a workgroup owns event i = blockIdx.y * WAVES + w
+// grid = (work list of (problem, subset chunk), ceil(N / WAVES)); wave w owns event i = blockIdx.y * WAVES + w
 // and strides the subsets S across its lanes; all reductions are wave-level.
 constexpr int GR_CHUNK = 13;                      // subsets per workgroup of k_grad_rows: 2^13
 
@@ -1550,13 +1550,15 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      const T* __restrict__ A,
                                                      const T* __restrict__ p,
                                                      const T* __restrict__ q, T* G, int kind,
-                                                     int maxhi, T* DJ) {
+                                                     int maxhi, T* DJ, const int2* __restrict__ chunks,
+                                                     int nprob) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][64]
   T* rowbuf = Tlo + WAVES * 64;                 // [WAVES][32]
   T* hiacc = rowbuf + WAVES * 32;               // [WAVES][maxhi][64]
   __shared__ int lev[32];                       // event of local bit l
-  const Desc& d = descs[blockIdx.x];
+  const int prob = chunks[blockIdx.x].x, chunk = chunks[blockIdx.x].y;   // (problem, subset chunk) work list
+  const Desc& d = descs[prob];
   const int N = d.N, n = N - 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int i = blockIdx.y * WAVES + w;
@@ -1577,8 +1579,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
   //    GK_E -> d_dp on the seed = 0 states, where D_m = 0)
   const bool drow = i == N;
   if (i > N || (drow && (kind == GK_S || DJ == nullptr))) return;
-  if (((long long)blockIdx.z << GR_CHUNK) >= (1ll << kc)) return;          // chunk beyond this problem's lattice
-  T* row = drow ? DJ + ((long long)kind * gridDim.x + blockIdx.x) * N : G + ((long long)blockIdx.x * N + i) * N;
+  T* row = drow ? DJ + ((long long)kind * nprob + prob) * N : G + ((long long)prob * N + i) * N;
   T* rb = rowbuf + w * 32;
   if (lane < 32) rb[lane] = 0;
   const T* fvec = drow ? (kind == GK_M ? P.dm : P.dp) : P.th[i < N ? i : 0];
@@ -1610,8 +1611,9 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       Ab = A + o;
     }
     const long long nS = 1ll << kc;
-    // workgroup z takes the subsets [z, z + 1) << GR_CHUNK (long lattices are split, partial rows are added up)
-    const long long Sbeg = (long long)blockIdx.z << GR_CHUNK;
+    // this workgroup takes the subsets [chunk, chunk + 1) << GR_CHUNK (long lattices are split, partial rows are
+    // added up)
+    const long long Sbeg = (long long)chunk << GR_CHUNK;
     const long long Send = nS < Sbeg + (1ll << GR_CHUNK) ? nS : Sbeg + (1ll << GR_CHUNK);
     T tot = 0;
     constexpr int GU = 4;                          // chunks of 64 subsets in flight per wave
