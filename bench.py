@@ -176,6 +176,8 @@ def main():
                         "frac_of_peak": mult * V * kb / ms / 1e6 / HBM_PEAK_GBPS, "batch": kb,
                         "alg_bytes_per_launch": mult * V * kb}
         tr_kv = traffic.get("kronvec", {}) if (n == 20 and kb == 64 and a.dtype == "f64") else {}
+        ek = traffic.get("eval_kernels", {}) if (n == 20 and a.dtype == "f64") else {}
+        solve_traffic = (ek["k_psolve_fwd"]["bytes_per_patient"] + ek["k_psolve_adj"]["bytes_per_patient"]) if ek else None
         kern_ms = cnt["sweep_ms"] / max(cnt["sweep_launches"], 1)
         achieved = cnt["sweep_alg_bytes"] / max(cnt["sweep_ms"], 1e-9) / 1e6      # GB/s
         b_pat = (7 * (n + 1) + 4) * (2 ** n) * (8 if a.dtype == "f64" else 4)      # Jacobi-formulation floor per patient
@@ -188,7 +190,7 @@ def main():
                                    f"2^{n}-state vectors, {a.dtype} (BASELINE.json configs[2] per GPU)",
                        "patients_total": world * a.patients, "perc_met": 0.5, "penalty": "symmetric_penal 1e-3",
                        "parallelism": f"patient-shard x{world}, one all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval",
-                       "solver": os.environ.get("MMHN_SOLVER", "substitution (k_tsolve)"),
+                       "solver": os.environ.get("MMHN_SOLVER", "substitution (k_psolve per patient, k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
             # kronvec kernel k_sweep<T,false>: the unit of SURVEY 8(d) (B_kv = 2 * 2^k * s per vector), measured live above
             "roofline": {"bound": "hbm", "achieved": kv["kronvec"]["alg_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -197,13 +199,21 @@ def main():
                          "avg_launch_ms": kv["kronvec"]["ms_per_launch"],
                          "alg_bytes_per_launch": kv["kronvec"]["alg_bytes_per_launch"],
                          "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)" if tr_kv else None},
-            # dominant kernel of the evaluation itself: the substitution solve; its compulsory traffic is only the
-            # solution it writes (+ a dense right-hand side when there is one), far below the Jacobi floor by design
+            # dominant kernels of the evaluation itself: the two substitution solves (one workgroup per patient).
+            # Algorithmic bytes = the solution written once; the PMC traffic is ~5x that - every tile re-reads the
+            # solved neighbour tiles it depends on - and both k_psolve and k_pclass run at the ~3.7 TB/s this chip
+            # sustains for such mixed read/write streams (profiles/README.md)
             "roofline_solver": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                                "kernel": "k_tsolve (tile-level substitution solve), HIP events inside the timed region",
+                                "frac": achieved / HBM_PEAK_GBPS,
+                                "traffic": (solve_traffic * a.patients / 2.0) if solve_traffic else None,
+                                "traffic_GBps": (solve_traffic * a.patients * a.steps / (cnt["sweep_ms"] * 1e6)) if solve_traffic else None,
+                                "kernel": "k_psolve<double,false|true> (forward + adjoint substitution solve; the few-launch "
+                                          "k_tsolve solves of the marginal problems are in the same counters), HIP events "
+                                          "inside the timed region",
                                 "launches": int(cnt["sweep_launches"]), "avg_launch_ms": kern_ms,
-                                "alg_bytes_per_launch": cnt["sweep_alg_bytes"] / max(cnt["sweep_launches"], 1)},
+                                "solve_ms_per_eval": cnt["sweep_ms"] / a.steps,
+                                "alg_bytes_per_launch": cnt["sweep_alg_bytes"] / max(cnt["sweep_launches"], 1),
+                                "traffic_source": "profiles/r1_traffic.json eval_kernels (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE, per patient, mean of the two solves)" if solve_traffic else None},
             # the same evaluations priced at the reference formulation's floor B_pat = [7(k+1)+4] 2^k s per patient
             "eval_vs_jacobi_floor": {"B_pat_bytes": b_pat, "equivalent_GBps": b_pat * a.patients * world * a.steps / dt / 1e9,
                                      "note": "substitution solves move less than this floor; >8000 means faster than any Jacobi-sweep implementation could be on this chip"},
