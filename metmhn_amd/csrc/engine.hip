@@ -369,13 +369,14 @@ struct Engine : EngineBase {
 
   // joint solves with many patients in flight: one workgroup per patient, single launch (k_psolve)
   size_t psolve_lds(int maxk) const {
-    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t);
+    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB);
   }
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
     const int mk = std::max(b.maxkJ, 1);
-    const size_t lds = psolve_lds(mk);
+    size_t lds = psolve_lds(mk);
+    if (const char* pad = std::getenv("MMHN_PSOLVE_LDS_PAD")) lds += (size_t)std::atoi(pad);      // experiment: occupancy
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
     timed(bytes, [&]() {
       if (tr)

@@ -21,6 +21,9 @@
 #ifndef MMHN_ABL
 #define MMHN_ABL 0
 #endif
+#ifndef MMHN_PSX
+#define MMHN_PSX 0
+#endif
 namespace mmhn {
 
 #ifndef MMHN_TB
@@ -694,7 +697,8 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   T* Utab = Urow + maxk * 64;
   T* thc = Utab + maxk * 64;
   T* hx = thc + maxk * maxk;
-  uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries + 3 per-tile high parts
+  uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries
+  uint16_t* pml = reinterpret_cast<uint16_t*>(pxt + 400);       // popcount order of the tile's states
   const int tid0 = threadIdx.x;
   int tid = tid0;
   const int prob = blockIdx.x;
@@ -723,7 +727,10 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
     const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
     pxt[tid] = half == 0 ? pext32((uint32_t)v, m & 63u) : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
   }
-  const uint16_t* pm = perm + (size_t)t * (1 << TB);
+  {
+    const uint16_t* pm = perm + (size_t)t * (1 << TB);
+    for (uint32_t e = tid; e < nelem; e += TSB) pml[e] = pm[e];
+  }
   const T* dP = tab + toff + rate_table_size(k);
   const T* dM = dP + (1ll << __popc(maskP));
   const T* dE = dM + (1ll << __popc(maskM));
@@ -732,6 +739,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
   if (rhs_mode == 3) Lk = links[prob];
   __syncthreads();
 
+  uint32_t Hprev = 0xffffffffu;                                 // tile whose solution yt still holds
   for (int it = 0; it < ntile; ++it) {
     const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
     const uint32_t xhi = H << t;
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
         acc[j] = (xl < nelem && (xhi | xl) == 0) ? e0_scale<T>() : T(0);
       }
     }
-    __syncthreads();                                   // Utab complete
+    __syncthreads();                                   // Utab complete; the previous tile's stores have landed
     const bool fast = t == TB && seedb >= t && seed_hi;
     // ---- step A: transitions that cross the tile boundary
 #if MMHN_ABL != 1
@@ -818,10 +826,16 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
         const int b = t + __ffs(mb) - 1;
         mb &= mb - 1;
         const T Lb = Ltab[b * 64 + lane];
-        const T* yn = y + base + (xhi ^ (1u << b));
         T nf[NJ];
+        if (!(MMHN_PSX & 2) && (H ^ (1u << (b - t))) == Hprev) {
+          // the neighbour is the tile this workgroup solved last: still in yt (this thread's own slots)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) nf[j] = yn[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
+          for (int j = 0; j < NJ; ++j) nf[j] = yt[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
+        } else {
+          const T* yn = y + base + (xhi ^ (1u << b));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) nf[j] = yn[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] += Lb * Utab[b * 64 + wave + NW * j] * nf[j];
       }
@@ -844,7 +858,11 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t idx = (uint32_t)tid + TSB * j;
-      px[j] = idx < nelem ? pm[idx] : 0u;
+#if MMHN_PSX & 1
+      px[j] = idx < nelem ? perm[(size_t)t * (1 << TB) + idx] : 0u;
+#else
+      px[j] = idx < nelem ? pml[idx] : 0u;
+#endif
       plev[j] = idx < nelem ? __popc(px[j]) : -1;
     }
     T lid[NJ];
@@ -907,9 +925,17 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
       __syncthreads();
     }
 #endif
-    // ---- step C (the barrier also makes the tile visible to this workgroup's later neighbour reads)
+    // ---- step C
     for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
+    Hprev = H;
+    // LDS-only barrier (Utab / yt are rewritten next); the stores are waited for by the full barrier that
+    // precedes the next tile's neighbour loads
+#if MMHN_PSX & 4
     __syncthreads();
+#else
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+#endif
   }
 }
 
