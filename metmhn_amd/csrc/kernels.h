@@ -891,16 +891,19 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
         uint32_t todo = TR ? (~xl & tmask) : xl;
         if (fast) {
           while (todo) {
-            T r[3];
+            T lv[3], uv[3], yv[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const bool on = todo != 0;
               const int b = on ? __ffs(todo) - 1 : 0;
               todo &= todo - 1;
               const uint32_t yi = on ? (xl ^ (1u << b)) : (1u << TB);      // padded slot reads the zero
-              r[u] = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[yi];
+              lv[u] = Ltab[b * 64 + lo];
+              uv[u] = Utab[b * 64 + ro];
+              yv[u] = yt[yi];
             }
-            z += r[0] + r[1] + r[2];
+            asm volatile("" ::: "memory");                 // all nine LDS reads in flight before the first use
+            z += lv[0] * uv[0] * yv[0] + lv[1] * uv[1] * yv[1] + lv[2] * uv[2] * yv[2];
           }
         } else {
           const uint32_t x = xhi | xl;
