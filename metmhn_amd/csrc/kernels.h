@@ -67,6 +67,15 @@ __device__ __forceinline__ bool seed_set(const Desc& d, uint32_t x) {
   return d.mode == SINGLE || (d.seedbit >= 0 && ((x >> d.seedbit) & 1u));
 }
 
+// Can any state of the tile with high part xhi (seeding set) be reached by the seeding event, i.e. is x ^ seed a
+// PT == MT state for some in-tile part?  Decided on the tile bits alone (a pair straddling the tile boundary
+// stays undecided): most seeded tiles of a large space fail it and skip the seed = 0 neighbour tile.
+__device__ __forceinline__ bool seed_move_possible(uint32_t lone, uint32_t pairP, uint32_t xhi, uint32_t tmask) {
+  if (xhi & lone & ~tmask) return false;
+  const uint32_t pp = pairP & ~tmask;
+  return ((xhi & pp) << 1) == (xhi & (pp << 1));
+}
+
 // ------------------------------------------------------------------------------------
 // k_prep: per-problem tables, rebuilt once per evaluation (theta changes, the bit roles do not).
 // Layout at tab + d.toff (T elements):
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
       const bool has = (xhi & bit) != 0;
       const bool is_seed = joint && b == d.seedbit;
       if (is_seed ? TR : (TR ? has : !has)) continue;     // seeding enters these tiles only in Q (not Q^T)
+      if (is_seed && !seed_move_possible(d.lone, d.pairP, xhi, tmask)) continue;
       const T Lb = Ltab[b * 64 + lane];
       T nv[NJ];
 #pragma unroll
@@ -380,6 +390,25 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
   }
   // kind == 1: Q_off has no entries in this tile, acc stays 0
 
+  if (!lidg && t == TB) {
+    // plain product on a full tile: y is not read again by this launch, so it leaves through LDS as 16-byte
+    // write-through stores that do not stay in the XCD's L2 (`sc0 sc1`; 8-byte ones would cost 2.7x per byte) -
+    // the L2 then keeps the p tiles that later tiles read as neighbours
+    if (kind != 1) {
+      __syncthreads();                           // every neighbour read of the staged p tile is done
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) tile[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane] = acc[j];
+      __syncthreads();
+    }
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int PER = 16 / sizeof(T);          // elements per 16-byte store
+    for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
+      f32x4 val = kind != 1 ? *reinterpret_cast<const f32x4*>(&tile[e]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      T* dst = y + base + xhi + e;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int r = wave + NW * j;
@@ -839,7 +868,7 @@ __global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ desc
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] += Lb * Utab[b * 64 + wave + NW * j] * nf[j];
       }
-      if (!TR) gen_move(seedb, 0);
+      if (!TR && seed_move_possible(lone, pairP, xhi, tmask)) gen_move(seedb, 0);
     } else {
       for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
         gen_move(b, 0);
