@@ -101,6 +101,17 @@ int mmhn_v_resolvent(mmhn_handle h, const double* log_theta, const int8_t* state
 int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* log_theta, const int8_t* state,
                          const double* x, const double* y, double* G, double* d_diag);
 
+/* ---- simulation ---------------------------------------------------------
+ * mmhn_simulate: Gillespie sampler of the joint PT/MT process, one trajectory per thread; replaces
+ * metmhn/simulations.py:117-147 (`simulate_dat`) and :87-114 (`simulate_orders`).
+ *   log_theta [N][N], pt_d_ef / mt_d_ef [N]: log-parameters as the reference passes them (N = n_mut + 1)
+ *   seed: Philox key; the samples depend on (seed, n_sim index) only
+ *   dat_out    int8 [n_sim][2 n_mut + 2] = [PT_0, MT_0, ..., seeding, order (0 unpaired / 1 PT first / 2 MT first)]
+ *   orders_out int8 [n_sim][2 N + 2] event sequences padded with -99 (events numbered as simulations.py:100-107), or NULL
+ */
+int mmhn_simulate(mmhn_handle h, const double* log_theta, const double* pt_d_ef, const double* mt_d_ef,
+                  int64_t n_sim, uint64_t seed, int8_t* dat_out, int8_t* orders_out);
+
 /* ---- measurement -------------------------------------------------------------------
  * mmhn_bench_kronvec: `batch` resident copies of a 2^k vector, `iters` back-to-back
  * launches of the batched Q_off p kernel (or the fused Jacobi step if jacobi != 0) timed

@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("engine.hip", "kernels.h", "desc.h")]
+_SRC = [os.path.join(_HERE, "csrc", f) for f in ("engine.hip", "kernels.h", "desc.h", "sampler.h")]
 _HDR = os.path.join(_ROOT, "include", "metmhn_amd.h")
 LIB_PATH = os.environ.get("MMHN_LIB", os.path.join(_HERE, "libmetmhn_amd.so"))   # MMHN_LIB: A/B builds
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "mmhn_v_resolvent": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, C.c_int],
     "mmhn_v_x_partial_Q_y": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, f64p],
     "mmhn_bench_kronvec": [C.c_void_p, f64p, i8p, C.c_int64, C.c_int, C.c_int, C.c_int, f64p],
+    "mmhn_simulate": [C.c_void_p, f64p, f64p, f64p, C.c_int64, C.c_uint64, i8p, i8p],
     "mmhn_get_counters": [C.c_void_p, C.POINTER(Counters)],
     "mmhn_reset_counters": [C.c_void_p],
 }

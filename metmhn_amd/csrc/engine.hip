@@ -27,6 +27,7 @@
 
 #include "../../include/metmhn_amd.h"
 #include "kernels.h"
+#include "sampler.h"
 
 namespace mmhn {
 
@@ -1128,6 +1129,34 @@ int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, c
   const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
   DISPATCH(h, api_xQy_single(d, x, y, G, d_diag));
+  API_END
+}
+
+// ---- Gillespie sampler
+int mmhn_simulate(mmhn_handle h, const double* lt, const double* pt_d_ef, const double* mt_d_ef, int64_t n_sim,
+                  uint64_t seed, int8_t* dat_out, int8_t* orders_out) {
+  API_BEGIN
+  REQUIRE(h && lt && pt_d_ef && mt_d_ef && dat_out, "null pointer");
+  REQUIRE(n_sim >= 0, "n_sim must be non-negative");
+  const int N = h->n + 1;
+  REQUIRE(N <= SIM_MAXN, "too many events for the sampler");
+  if (n_sim > 0) {
+    const size_t W = (size_t)2 * h->n + 2, L = (size_t)2 * N + 2;
+    DevArr<double> d_lt, d_dp, d_dm;
+    DevArr<int8_t> d_dat, d_ord;
+    d_lt.alloc((size_t)N * N); d_dp.alloc(N); d_dm.alloc(N); d_dat.alloc((size_t)n_sim * W);
+    if (orders_out) d_ord.alloc((size_t)n_sim * L);
+    HIPCHECK(hipMemcpy(d_lt.p, lt, sizeof(double) * N * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_dp.p, pt_d_ef, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_dm.p, mt_d_ef, sizeof(double) * N, hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)((n_sim + SIM_BLOCK - 1) / SIM_BLOCK);
+    hipLaunchKernelGGL(k_gillespie, dim3(grid), dim3(SIM_BLOCK), 0, 0, d_lt.p, d_dp.p, d_dm.p, N, (long long)n_sim, seed,
+                       d_dat.p, orders_out ? d_ord.p : nullptr);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(dat_out, d_dat.p, (size_t)n_sim * W, hipMemcpyDeviceToHost));
+    if (orders_out) HIPCHECK(hipMemcpy(orders_out, d_ord.p, (size_t)n_sim * L, hipMemcpyDeviceToHost));
+  }
   API_END
 }
 

@@ -174,6 +174,18 @@ class Engine:
                                                  dd.ctypes.data_as(f64p)))
         return G, dd
 
+    # ---- simulation
+    def simulate(self, log_theta, pt_d_ef, mt_d_ef, n_sim, seed=0, orders=False):
+        """Gillespie samples: int8 dat [n_sim, 2n+2] (and the event sequences [n_sim, 2N+2] if `orders`)."""
+        lt, ltp = _f(log_theta); a, ap = _f(pt_d_ef); b, bp = _f(mt_d_ef)
+        n_sim = int(n_sim)
+        dat = np.zeros((n_sim, 2 * self.n + 2), dtype=np.int8)
+        od = np.zeros((n_sim, 2 * self.N + 2), dtype=np.int8) if orders else None
+        _lib.check(self.lib.mmhn_simulate(self.h, ltp, ap, bp, n_sim, int(seed) & (2 ** 64 - 1),
+                                          dat.ctypes.data_as(_lib.i8p),
+                                          od.ctypes.data_as(_lib.i8p) if orders else None))
+        return (dat, od) if orders else dat
+
     # ---- measurement
     def bench_kronvec(self, log_theta, state, batch, iters, transpose=False, jacobi=False):
         lt, ltp = _f(log_theta); st, sp = _s(state)
