@@ -33,31 +33,50 @@ def indep(dat) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
     return theta, np.zeros(n + 1), np.zeros(n + 1)
 
 
-def cross_val(dat, penal_fun: Callable, splits, n_folds: int, m_p_corr: float, key: int = 42):
+def cross_val(dat, penal_fun: Callable, splits, n_folds: int, m_p_corr: float, key: int = 42,
+              parallel_folds: bool = False, _learn=None, _score=None):
     """n_folds cross-validation over the penalty weights `splits` (Utilityfunctions.py:186-231).
 
     `key` seeds a NumPy Generator for the row permutation (the reference uses jax.random.permutation;
     the fold assignment therefore differs from the reference's for the same key, the procedure does not).
     Returns a DataFrame [n_folds x len(splits)] of held-out scores.
+
+    `parallel_folds`: the len(splits) x n_folds fits are independent, so under torch.distributed (one process
+    per GPU) rank r takes the jobs `distributed.fold_jobs` assigns to it, fits them on its own GPU with the whole
+    training fold (no patient sharding inside a fit) and ONE all-reduce of the score matrix at the end gives every
+    rank the full table.  Without an initialised process group it is the plain loop.
     """
     import pandas as pd
+    from . import distributed as D
+    from . import regularized_optimization as ro
+    learn = learn_mhn if _learn is None else _learn
+    score_fn = score if _score is None else _score
     dat = np.asarray(dat)
     splits = np.asarray(splits, dtype=np.float64)
     rng = np.random.default_rng(key)
     shuffled = dat[rng.permutation(dat.shape[0])]
     runs = np.zeros((n_folds, splits.shape[0]))
     batch_size = int(np.ceil(dat.shape[0] / n_folds))
+    rank, world = ro._rank_world() if parallel_folds else (0, 1)
+    prev_shard = ro._OPTIONS["shard"]
+    if world > 1:
+        ro.configure(device=ro._OPTIONS["device"], dtype=ro._OPTIONS["dtype"], shard=False)
     logging.info("Crossvalidation started")
-    for i in range(splits.size):
-        for fold in range(n_folds):
+    try:
+        for i, fold in D.fold_jobs(splits.size, n_folds, rank, world):
             n_dat = shuffled.shape[0]
             start = batch_size * fold
             stop = min(batch_size * (fold + 1), n_dat)
             train = np.concatenate((shuffled[:start], shuffled[stop:]))
             th0, dp0, dm0 = indep(train)
-            th, dp, dm = learn_mhn(th0, dp0, dm0, train, m_p_corr, penal_fun, splits[i], opt_v=False)
-            runs[fold, i] = score(th, dp, dm, shuffled[start:stop], m_p_corr)
+            th, dp, dm = learn(th0, dp0, dm0, train, m_p_corr, penal_fun, splits[i], opt_v=False)
+            runs[fold, i] = score_fn(th, dp, dm, shuffled[start:stop], m_p_corr)
             logging.info(f"Lambda: {splits[i]} Fold: {fold} Test Score: {runs[fold, i]}")
+    finally:
+        if world > 1:
+            ro.configure(device=ro._OPTIONS["device"], dtype=ro._OPTIONS["dtype"], shard=prev_shard)
+    if world > 1:
+        runs = D.allreduce_sums(runs.ravel()).reshape(runs.shape)
     return pd.DataFrame(runs, columns=splits, index=np.arange(n_folds))
 
 

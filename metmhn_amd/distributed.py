@@ -37,6 +37,13 @@ def shard_rows(dat: np.ndarray, world_size: int) -> list[np.ndarray]:
     return [np.sort(np.array(p, dtype=np.int64)) for p in parts]
 
 
+def fold_jobs(n_lambda: int, n_folds: int, rank: int = 0, world_size: int = 1) -> list[tuple[int, int]]:
+    """(penalty index, fold) jobs of cross_val owned by `rank`: the reference's loop order (Utilityfunctions.py:
+    207-208), dealt round-robin so that every rank gets the same number of fits (+-1)."""
+    jobs = [(i, f) for i in range(n_lambda) for f in range(n_folds)]
+    return jobs[rank::world_size]
+
+
 def allreduce_sums(sums: np.ndarray, group=None) -> np.ndarray:
     """Sum the partial-sum buffers of all ranks (no-op without an initialised process group)."""
     import torch

@@ -136,6 +136,56 @@ def test_two_rank_gloo_allreduce_reproduces_full_cohort(golden):
     np.testing.assert_allclose(res[3], g["c1_d_dm"], rtol=1e-10, atol=1e-13)
 
 
+def _cv_stub_learn(th0, dp0, dm0, train, m_p_corr, penal, w, opt_v=False):
+    return th0 + w, dp0, dm0                    # stands in for the optimizer (GPU-only); depends on lambda
+
+
+def _cv_stub_score(th, dp, dm, test, m_p_corr):
+    from oracle import metmhn_oracle as O
+    return O.score(th, dp, dm, test, m_p_corr)
+
+
+def _cv_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metmhn_amd.Utilityfunctions import cross_val
+    import metmhn_amd.regularized_optimization as ro
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cohorts.npz"))
+    df = cross_val(g["c1_dat"], ro.symmetric_penal, [1e-3, 1e-2, 1e-1], 3, 0.4, key=3, parallel_folds=True,
+                   _learn=_cv_stub_learn, _score=_cv_stub_score)
+    q.put((rank, df.to_numpy()))
+    dist.destroy_process_group()
+
+
+def test_fold_parallel_cross_val_two_ranks(golden):
+    """cross_val with the 3 x 3 independent fits dealt over 2 ranks (gloo) == the sequential loop; every rank
+    ends with the full table.  The optimizer / scorer are CPU stand-ins (the engine needs a GPU)."""
+    import torch.multiprocessing as mp
+    from metmhn_amd import distributed as D
+    from metmhn_amd.Utilityfunctions import cross_val
+    import metmhn_amd.regularized_optimization as ro
+    jobs = [D.fold_jobs(3, 3, r, 2) for r in range(2)]
+    assert sorted(jobs[0] + jobs[1]) == [(i, f) for i in range(3) for f in range(3)] and abs(len(jobs[0]) - len(jobs[1])) <= 1
+    g = golden("cohorts")
+    ref = cross_val(g["c1_dat"], ro.symmetric_penal, [1e-3, 1e-2, 1e-1], 3, 0.4, key=3,
+                    _learn=_cv_stub_learn, _score=_cv_stub_score).to_numpy()
+    assert np.isfinite(ref).all() and len(np.unique(ref)) == ref.size
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(got[r], ref, rtol=1e-13)
+
+
 def test_synthetic_generators():
     from metmhn_amd import synthetic
     d = synthetic.full_k_cohort(12, 50)
