@@ -442,7 +442,11 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
 // Same result as the Jacobi iteration up to rounding (Q_off is nilpotent), 1/(k+1) of the
 // arithmetic and ~1/10 of the HBM traffic.
 // ------------------------------------------------------------------------------------
-constexpr int TSB = 1024;                    // threads per workgroup of k_tsolve
+#ifndef MMHN_TSB
+#define MMHN_TSB 1024
+#endif
+constexpr int TSB = MMHN_TSB;                // threads per workgroup of k_tsolve / k_psolve
+constexpr int TSB_WPE = TSB == 1024 ? 8 : 4; // waves per SIMD the register budget is sized for (two workgroups per CU)
 
 __device__ __forceinline__ uint32_t pext32(uint32_t x, uint32_t mask) {
   uint32_t out = 0, pos = 0;
@@ -458,7 +462,7 @@ __device__ __forceinline__ uint32_t pext32(uint32_t x, uint32_t mask) {
 // LIDGV: 1/(D - diag Q) comes from the vector `lidg` (API path, single-tumour spaces);
 // otherwise from the class tables of k_prep (joint spaces with seeding: engine path).
 template <typename T, bool TR, bool LIDGV>
-__global__ __launch_bounds__(TSB, 8) void k_tsolve(const Desc* __restrict__ descs,
+__global__ __launch_bounds__(TSB, TSB_WPE) void k_tsolve(const Desc* __restrict__ descs,
                                                 const int2* __restrict__ lmap,
                                                 const Params<T>* __restrict__ par, T* y,
                                                 const T* __restrict__ lidg,
@@ -710,7 +714,7 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 // Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
 // ------------------------------------------------------------------------------------
 template <typename T, bool TR>
-__global__ __launch_bounds__(TSB, 8) void k_psolve(const Desc* __restrict__ descs,
+__global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
                                                    const int* __restrict__ pt_off,
                                                    const uint16_t* __restrict__ ptiles,
                                                    const Params<T>* __restrict__ par, T* y, int rhs_mode,

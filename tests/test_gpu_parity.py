@@ -175,6 +175,46 @@ def test_synthetic_cohort_against_oracle():
     np.testing.assert_allclose(gdm, b2, rtol=RTOL, atol=1e-9)
 
 
+def test_random_patients_against_c_oracle(monkeypatch):
+    """Randomised sweep: n = 1..9 events, every type / order code (incl. -99 and invalid order values on paired
+    rows), dense and sparse genotypes, empty and full rows; per-patient log-prob and gradients from both kernel
+    schedules (per tile, per patient) against the C restatement of the reference pass structure."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    cref.load()
+    rng = np.random.default_rng(20240807)
+    for n in (1, 2, 3, 5, 7, 9):
+        lt, dp, dm = synthetic.random_params(n, seed=100 + n)
+        rows = []
+        for _ in range(60):
+            dens = rng.choice([0.0, 0.15, 0.5, 0.85, 1.0])
+            bits = (rng.random(2 * n) < dens).astype(np.int8)
+            typ = int(rng.integers(0, 4))
+            if typ == 0:
+                bits[1::2] = 0
+                rows.append(np.concatenate((bits, [0, -99, 0])))
+            elif typ == 1:
+                bits[1::2] = 0
+                rows.append(np.concatenate((bits, [1, -99, 1])))
+            elif typ == 2:
+                bits[0::2] = 0
+                rows.append(np.concatenate((bits, [1, -99, 2])))
+            else:
+                rows.append(np.concatenate((bits, [1, int(rng.choice([0, 1, 2, -99, 3])), 3])))
+        dat = np.array(rows, dtype=np.int8)
+        lp, g, a, b = cref.patients(lt, dp, dm, dat, with_grad=True)
+        for pmin in ("1", "1000000"):
+            monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+            e = Engine(n)
+            e.set_cohort(dat)
+            r = e.patient_grads(lt, dp, dm)
+            e.close()
+            np.testing.assert_allclose(r[0], lp, rtol=1e-9, atol=1e-12, err_msg=f"n={n} lp pmin={pmin}")
+            np.testing.assert_allclose(r[1], g, rtol=1e-8, atol=1e-10, err_msg=f"n={n} d_theta pmin={pmin}")
+            np.testing.assert_allclose(r[2], a, rtol=1e-8, atol=1e-10, err_msg=f"n={n} d_dp pmin={pmin}")
+            np.testing.assert_allclose(r[3], b, rtol=1e-8, atol=1e-10, err_msg=f"n={n} d_dm pmin={pmin}")
+
+
 def test_small_batches_match_one_batch(engines):
     """A tiny workspace limit forces many batches: same result."""
     from metmhn_amd import Engine, synthetic
