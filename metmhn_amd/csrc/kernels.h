@@ -304,18 +304,22 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
   if (kind == 0) {
     // ---- fast path: every bit is a plain single-bit move
     const int nlane = t < 6 ? t : 6;
-    // lane bits: neighbour = other lane of the same row (wave shuffle)
+    // lane bits: neighbour = other lane of the same row, read from the staged tile (one conflict-free
+    // ds_read_b64 per state instead of two ds_bpermute)
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       if (b < nlane) {
         const T Lb = Ltab[b * 64 + lane];
         const bool has = (lane >> b) & 1;
         const bool on = TR ? !has : has;
+        const uint32_t nl = (uint32_t)lane ^ (1u << b);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int r = wave + NW * j;
-          const T nb = __shfl_xor(v[j], 1 << b);
-          if (r < R) acc[j] += on ? Lb * Utab[b * 64 + r] * nb : T(0);
+          if (r < R) {
+            const T nb = tile[((uint32_t)r << 6) | nl];
+            acc[j] += on ? Lb * Utab[b * 64 + r] * nb : T(0);
+          }
         }
       }
     }
@@ -330,20 +334,20 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
         if (r < R && (TR ? !has : has)) acc[j] += Lb * Utab[b * 64 + r] * tile[((r ^ rb) << 6) | lane];
       }
     }
-    // tile bits: neighbour = same position of another tile (coalesced global rows, batched)
+    // tile bits: neighbour = same position of another tile (coalesced global rows); the moves that apply to
+    // this tile are collected in a scalar bit set and taken two at a time (16 rows in flight per thread)
+    uint32_t mvs = 0;
     for (int b = t; b < k; ++b) {
       const uint32_t bit = 1u << b;
       const bool has = (xhi & bit) != 0;
       const bool is_seed = joint && b == d.seedbit;
       if (is_seed ? TR : (TR ? has : !has)) continue;     // seeding enters these tiles only in Q (not Q^T)
       if (is_seed && !seed_move_possible(d.lone, d.pairP, xhi, tmask)) continue;
+      mvs |= bit;
+    }
+    auto take = [&](int b, const T (&nv)[NJ]) {
+      const bool is_seed = joint && b == d.seedbit;
       const T Lb = Ltab[b * 64 + lane];
-      T nv[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-        nv[j] = xl < nelem ? p[base + ((xhi | xl) ^ bit)] : T(0);
-      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int r = wave + NW * j;
@@ -351,6 +355,27 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
         const bool on = r < R && xl < nelem && (!is_seed || eq_noseed(d, xhi | xl));
         acc[j] += on ? Lb * Utab[b * 64 + (r & 63)] * nv[j] : T(0);
       }
+    };
+    while (mvs) {
+      const int b0 = __ffs(mvs) - 1;
+      mvs &= mvs - 1;
+      const int b1 = mvs ? __ffs(mvs) - 1 : -1;
+      if (b1 >= 0) mvs &= mvs - 1;
+      T n0[NJ], n1[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+        n0[j] = xl < nelem ? p[base + ((xhi | xl) ^ (1u << b0))] : T(0);
+      }
+      if (b1 >= 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+          n1[j] = xl < nelem ? p[base + ((xhi | xl) ^ (1u << b1))] : T(0);
+        }
+      }
+      take(b0, n0);
+      if (b1 >= 0) take(b1, n1);
     }
   } else if (kind == 2) {
     // ---- generic path (seeding bit inside the tile, or seed = 0 tile with PT == MT states)
