@@ -376,8 +376,7 @@ struct Engine : EngineBase {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
     const int mk = std::max(b.maxkJ, 1);
-    size_t lds = psolve_lds(mk);
-    if (const char* pad = std::getenv("MMHN_PSOLVE_LDS_PAD")) lds += (size_t)std::atoi(pad);      // experiment: occupancy
+    const size_t lds = psolve_lds(mk);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
     timed(bytes, [&]() {
       if (tr)

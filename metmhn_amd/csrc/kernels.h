@@ -18,12 +18,6 @@
 #include <hip/hip_runtime.h>
 #include "desc.h"
 
-#ifndef MMHN_ABL
-#define MMHN_ABL 0
-#endif
-#ifndef MMHN_PSX
-#define MMHN_PSX 0
-#endif
 namespace mmhn {
 
 #ifndef MMHN_TB
@@ -846,7 +840,6 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     __syncthreads();                                   // Utab complete; the previous tile's stores have landed
     const bool fast = t == TB && seedb >= t && seed_hi;
     // ---- step A: transitions that cross the tile boundary
-#if MMHN_ABL != 1
     // one move (bit b; kind 1 = the pair move of P bit b) with every condition evaluated per state
     auto gen_move = [&](int b, int kind) {
       const bool is_seed = b == seedb;
@@ -885,7 +878,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
         mb &= mb - 1;
         const T Lb = Ltab[b * 64 + lane];
         T nf[NJ];
-        if (!(MMHN_PSX & 2) && (H ^ (1u << (b - t))) == Hprev) {
+        if ((H ^ (1u << (b - t))) == Hprev) {
           // the neighbour is the tile this workgroup solved last: still in yt (this thread's own slots)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) nf[j] = yt[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
@@ -904,7 +897,6 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
         if ((pairP >> b) & 1u) gen_move(b, 1);
       }
     }
-#endif
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
@@ -916,11 +908,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const uint32_t idx = (uint32_t)tid + TSB * j;
-#if MMHN_PSX & 1
-      px[j] = idx < nelem ? perm[(size_t)t * (1 << TB) + idx] : 0u;
-#else
       px[j] = idx < nelem ? pml[idx] : 0u;
-#endif
       plev[j] = idx < nelem ? __popc(px[j]) : -1;
     }
     T lid[NJ];
@@ -937,7 +925,6 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     }
     __syncthreads();
     // ---- step B: popcount-ordered substitution inside the tile
-#if MMHN_ABL != 2
     for (int s = 0; s <= t; ++s) {
       const int level = TR ? t - s : s;
 #pragma unroll
@@ -985,18 +972,13 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       }
       __syncthreads();
     }
-#endif
     // ---- step C
     for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
     Hprev = H;
     // LDS-only barrier (Utab / yt are rewritten next); the stores are waited for by the full barrier that
     // precedes the next tile's neighbour loads
-#if MMHN_PSX & 4
-    __syncthreads();
-#else
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
-#endif
   }
 }
 
