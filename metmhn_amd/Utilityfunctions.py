@@ -80,6 +80,22 @@ def cross_val(dat, penal_fun: Callable, splits, n_folds: int, m_p_corr: float, k
     return pd.DataFrame(runs, columns=splits, index=np.arange(n_folds))
 
 
+def create_dat(dat_sim_full, n_em: int, n_nm: int, n_c: int, n_pm: int, n_mo: int, rng) -> np.ndarray:
+    """Subsample simulated patients (rows of `simulate_dat`) to a cohort with the given composition and append
+    the type column (examples/recall_study.py:32-47): `n_nm` never-metastasised PT-only rows (type 0, all-zero
+    rows dropped first), and of the metastasised ones `n_c` paired (3), `n_mo` MT-only (2), `n_pm` PT-only (1).
+    `rng`: NumPy Generator (the reference draws the indices with jax.random.choice)."""
+    sim = np.asarray(dat_sim_full)
+    po = sim[sim[:, -2] == 0]
+    po = po[po.sum(axis=1) != 0]
+    po = po[rng.choice(po.shape[0], size=n_nm, replace=False)]
+    em = sim[sim[:, -2] != 0]
+    idx = rng.choice(em.shape[0], size=n_em, replace=False)
+    col = lambda rows, t: np.hstack((rows, np.full((rows.shape[0], 1), t, dtype=np.int8)))
+    out = np.vstack((col(po, 0), col(em[idx[:n_c]], 3), col(em[idx[n_c:n_c + n_mo]], 2), col(em[idx[n_c + n_mo:]], 1)))
+    return out.astype(np.int8)
+
+
 def categorize(x) -> int:
     """Type of a datapoint from its annotation (Utilityfunctions.py:98-113)."""
     import pandas as pd
