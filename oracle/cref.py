@@ -62,3 +62,37 @@ def kronvec(log_theta, p, state, diag=True, transpose=False):
     lib.ref_kronvec((st.shape[0] - 1) // 2, lt.ctypes.data_as(_f), st.ctypes.data_as(_i8), p.ctypes.data_as(_f),
                     y.ctypes.data_as(_f), int(diag), int(transpose))
     return y
+
+
+FAST = os.path.join(_HERE, "_build", "libmetmhn_fast.so")
+_fast = None
+
+
+def load_fast(build: bool = True):
+    """oracle/_build/libmetmhn_fast.so: optimised CPU variant (paired rows only; baseline / checker only)."""
+    global _fast
+    if _fast is None:
+        if build and (not os.path.exists(FAST) or os.path.getmtime(FAST) < os.path.getmtime(os.path.join(_HERE, "metmhn_fast.c"))):
+            subprocess.run(["make", "-s", "-C", _HERE], check=True)
+        _fast = C.CDLL(FAST)
+        _fast.fast_patients.argtypes = [C.c_int, _f, _f, _f, _i8, C.c_int64, C.c_int, _f, _f, _f, _f]
+    return _fast
+
+
+def fast_patients(log_theta, log_d_p, log_d_m, dat, threads=0):
+    """Per-patient (lp, d_theta, d_dp, d_dm) of PAIRED rows (type 3) by the gather formulation."""
+    lib = load_fast()
+    lt = np.ascontiguousarray(log_theta, dtype=np.float64)
+    dp = np.ascontiguousarray(log_d_p, dtype=np.float64)
+    dm = np.ascontiguousarray(log_d_m, dtype=np.float64)
+    dat = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+    n = (dat.shape[1] - 3) // 2
+    N, P = n + 1, dat.shape[0]
+    lp = np.zeros(P)
+    g, a, b = np.zeros((P, N, N)), np.zeros((P, N)), np.zeros((P, N))
+    rc = lib.fast_patients(n, lt.ctypes.data_as(_f), dp.ctypes.data_as(_f), dm.ctypes.data_as(_f),
+                           dat.ctypes.data_as(_i8), P, int(threads), lp.ctypes.data_as(_f),
+                           g.ctypes.data_as(_f), a.ctypes.data_as(_f), b.ctypes.data_as(_f))
+    if rc != 0:
+        raise ValueError(f"row {rc - 1} is not a paired datapoint with seeding")
+    return lp, g, a, b

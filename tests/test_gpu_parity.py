@@ -215,6 +215,29 @@ def test_random_patients_against_c_oracle(monkeypatch):
             np.testing.assert_allclose(r[3], b, rtol=1e-8, atol=1e-10, err_msg=f"n={n} d_dm pmin={pmin}")
 
 
+def test_full_size_patients_against_optimised_cpu_variant(monkeypatch):
+    """BASELINE configs[2] at full size: n = 20, k = 20 (2^20-state vectors) paired patients, per-patient
+    log-prob and gradients from both kernel schedules against oracle/metmhn_fast.c (an independent CPU
+    implementation of the same mathematics, itself pinned to the reference-structure port on small cases)."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 20
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 12, seed=2000 + n)
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    for pmin in ("1", "1000000"):
+        monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+        e = Engine(n)
+        e.set_cohort(dat)
+        r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], lp, rtol=1e-10)
+        np.testing.assert_allclose(r[1], g, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
+
+
 def test_small_batches_match_one_batch(engines):
     """A tiny workspace limit forces many batches: same result."""
     from metmhn_amd import Engine, synthetic

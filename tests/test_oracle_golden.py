@@ -136,3 +136,27 @@ def test_gradient_is_fd_of_score():
         e = np.zeros(4); e[i] = h
         assert abs((O.score(lt, dp + e, dm, dat, .4) - O.score(lt, dp - e, dm, dat, .4)) / (2 * h) - gdp[i]) < 1e-7
         assert abs((O.score(lt, dp, dm + e, dat, .4) - O.score(lt, dp, dm - e, dat, .4)) / (2 * h) - gdm[i]) < 1e-7
+
+
+def test_optimised_cpu_variant_matches_reference_structure_port():
+    """oracle/metmhn_fast.c (gather formulation, substitution solves; second CPU baseline of bench.py) against
+    oracle/metmhn_ref.c (reference pass structure) on random paired rows: every order code, sparse / dense /
+    empty / full genotypes, n = 3, 5, 8."""
+    from oracle import cref
+    from metmhn_amd import synthetic
+    rng = np.random.default_rng(5)
+    for n in (3, 5, 8):
+        lt, dp, dm = synthetic.random_params(n, seed=50 + n)
+        rows = []
+        for _ in range(30):
+            bits = (rng.random(2 * n) < rng.choice([0.1, 0.5, 0.9])).astype(np.int8)
+            rows.append(np.concatenate((bits, [1, int(rng.choice([0, 1, 2, -99])), 3])))
+        rows.append(np.concatenate((np.zeros(2 * n, np.int8), [1, 0, 3])))
+        rows.append(np.concatenate((np.ones(2 * n, np.int8), [1, 2, 3])))
+        dat = np.array(rows, dtype=np.int8)
+        a = cref.patients(lt, dp, dm, dat)
+        b = cref.fast_patients(lt, dp, dm, dat)
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(y, x, rtol=1e-11, atol=1e-13)
+    with pytest.raises(ValueError):
+        cref.fast_patients(lt, dp, dm, np.array([[1, 0] * n + [1, -99, 1]], dtype=np.int8))
