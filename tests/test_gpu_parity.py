@@ -236,6 +236,22 @@ def test_full_size_patients_against_optimised_cpu_variant(monkeypatch):
         np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
+    # 300 patients at n = 16 with k = 10..16 active slots: PT / MT splits from 1 : 15 to 15 : 1 (class bits above the
+    # class-aligned tile, partial tiles, lone-heavy and pair-heavy layouts)
+    n = 16
+    lt, dp, dm = synthetic.random_params(n, seed=77)
+    dat = np.vstack([synthetic.full_k_cohort(n, 50, k=kk, seed=900 + kk) for kk in (10, 12, 13, 14, 15, 16)])
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    for pmin in ("1", "1000000"):
+        monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+        e = Engine(n)
+        e.set_cohort(dat)
+        r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], lp, rtol=1e-10)
+        np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
 
 
 def test_small_batches_match_one_batch(engines):
