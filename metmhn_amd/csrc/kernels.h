@@ -1471,11 +1471,14 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
     uint32_t goff[NST], eo[NST];
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
-      const uint32_t m = (uint32_t)tid + CMB * u;
+      // a thread takes pairs of memory-adjacent tile elements (2 j, 2 j + 1): one 16-byte load when index bit 0
+      // is a tile bit
+      const uint32_t m = 2u * ((uint32_t)tid + CMB * (u >> 1)) + (u & 1);
       const uint32_t g = pdep32(m, tilemask);
       goff[u] = g;
       eo[u] = m < nelem2 ? pext32(g, clow) + RS * pext32(g, fill) : 0xffffffffu;
     }
+    const bool wide = (tilemask & 1u) && nelem2 >= 2;     // then goff[2 j + 1] = goff[2 j] + 1, both valid or both not
     __syncthreads();                                      // previous class done with the staged tile
     for (int e = tid; e < PC_LDS_ELEMS; e += CMB) pt[e] = T(0);
     const uint32_t nrows1 = nelem2 > 64 ? nelem2 >> 6 : 1;   // rows of 64 states (a small tile is one partial row)
@@ -1494,11 +1497,24 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
         {
           const long long base = off + (long long)(obase | cbase);
           T rp[NST], rq[NST];
+          if (wide) {
+            struct alignas(2 * sizeof(T)) pair_t { T a, b; };
 #pragma unroll
-          for (int u = 0; u < NST; ++u) {
-            const bool ok = eo[u] != 0xffffffffu;
-            rp[u] = ok ? p[base + goff[u]] : T(0);
-            rq[u] = ok ? q[base + goff[u]] : T(0);
+            for (int u = 0; u < NST; u += 2) {
+              pair_t vp{T(0), T(0)}, vq{T(0), T(0)};
+              if (eo[u] != 0xffffffffu) {
+                vp = *reinterpret_cast<const pair_t*>(p + base + goff[u]);
+                vq = *reinterpret_cast<const pair_t*>(q + base + goff[u]);
+              }
+              rp[u] = vp.a; rp[u + 1] = vp.b; rq[u] = vq.a; rq[u + 1] = vq.b;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+              const bool ok = eo[u] != 0xffffffffu;
+              rp[u] = ok ? p[base + goff[u]] : T(0);
+              rq[u] = ok ? q[base + goff[u]] : T(0);
+            }
           }
           __syncthreads();                                // previous tile reduced
 #pragma unroll
@@ -1525,7 +1541,7 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
           const long long nb = off + (long long)(obase | pdep32(Shi | (1u << hb), chigh));
           T rq[NST];
 #pragma unroll
-          for (int u = 0; u < NST; ++u) rq[u] = eo[u] != 0xffffffffu ? q[nb + goff[u]] : T(0);
+          for (int u = 0; u < NST; ++u) rq[u] = eo[u] != 0xffffffffu ? q[nb + goff[u]] : T(0);   // (8-byte loads: rare path)
           __syncthreads();
 #pragma unroll
           for (int u = 0; u < NST; ++u)
