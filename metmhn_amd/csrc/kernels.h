@@ -1482,14 +1482,17 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
     __syncthreads();                                      // previous class done with the staged tile
     for (int e = tid; e < PC_LDS_ELEMS; e += CMB) pt[e] = T(0);
     const uint32_t nrows1 = nelem2 > 64 ? nelem2 >> 6 : 1;   // rows of 64 states (a small tile is one partial row)
-    for (uint32_t Shi = 0; Shi < (1u << nh); ++Shi) {
-      T acc[2][PCA + 1], acch[2][PCH];
+    // one block of class settings (fixed bits above the tile); two instantiations so that the common case
+    // kc <= PCA carries no accumulators for slots above the tile
+    auto block = [&](auto hic, uint32_t Shi) {
+      constexpr bool HI = decltype(hic)::value;             // class bits above the tile exist (kc > PCA)
+      T acc[2][PCA + 1], acch[2][HI ? PCH : 1];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int j = 0; j <= PCA; ++j) acc[s][j] = T(0);
 #pragma unroll
-        for (int j = 0; j < PCH; ++j) acch[s][j] = T(0);
+        for (int j = 0; j < (HI ? PCH : 1); ++j) acch[s][j] = T(0);
       }
       const uint32_t cbase = pdep32(Shi, chigh);
       for (uint32_t o = 0; o < (1u << no); ++o) {
@@ -1536,7 +1539,7 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
         }
         // slots of the class bits above the tile: the neighbour block's q replaces qt for one pass each
 #pragma unroll
-        for (int hb = 0; hb < PCH; ++hb) {
+        for (int hb = 0; hb < (HI ? PCH : 0); ++hb) {
           if (hb >= nh || ((Shi >> hb) & 1u)) continue;
           const long long nb = off + (long long)(obase | pdep32(Shi | (1u << hb), chigh));
           T rq[NST];
@@ -1568,11 +1571,13 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
           if (j < a && !((Sl >> j) & 1u) && acc[s][1 + j] != T(0))
             atomicAdd(&out[((long long)(1 + j) << kc) + S], acc[s][1 + j]);
 #pragma unroll
-        for (int hb = 0; hb < PCH; ++hb)
+        for (int hb = 0; hb < (HI ? PCH : 0); ++hb)
           if (hb < nh && !((Shi >> hb) & 1u) && acch[s][hb] != T(0))
             atomicAdd(&out[((long long)(1 + a + hb) << kc) + S], acch[s][hb]);
       }
-    }
+    };
+    if (nh == 0) block(std::false_type{}, 0u);
+    else for (uint32_t Shi = 0; Shi < (1u << nh); ++Shi) block(std::true_type{}, Shi);
   }
 }
 
