@@ -972,8 +972,15 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       }
       __syncthreads();
     }
-    // ---- step C
-    for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
+    // ---- step C: 16 bytes per lane when the tile is full
+    if (t == TB) {
+      struct alignas(16) vec16 { T v[16 / sizeof(T)]; };
+      constexpr uint32_t PER = 16 / sizeof(T);
+      for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += TSB * PER)
+        *reinterpret_cast<vec16*>(y + base + xhi + e) = *reinterpret_cast<const vec16*>(yt + e);
+    } else {
+      for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
+    }
     Hprev = H;
     // LDS-only barrier (Utab / yt are rewritten next); the stores are waited for by the full barrier that
     // precedes the next tile's neighbour loads
