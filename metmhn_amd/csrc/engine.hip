@@ -335,7 +335,7 @@ struct Engine : EngineBase {
                         const DevArr<int2>& chunks, T* dj = nullptr) {
     if (nprob == 0 || chunks.n == 0) return;
     const int maxhi = std::max(0, maxk - 6);
-    const size_t lds = ((size_t)WAVES * 64 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
+    const size_t lds = ((size_t)WAVES * 192 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
     hipLaunchKernelGGL((k_grad_rows<T>), dim3((unsigned)chunks.n, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream,
                        descs, d_par.p, A, p, q, G, kind, maxhi, dj, chunks.p, nprob);

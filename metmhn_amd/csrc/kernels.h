@@ -1650,8 +1650,8 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      int maxhi, T* DJ, const int2* __restrict__ chunks,
                                                      int nprob) {
   extern __shared__ __align__(16) unsigned char smem[];
-  T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][64]
-  T* rowbuf = Tlo + WAVES * 64;                 // [WAVES][32]
+  T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][3][64]: rate products over subset bits 0-5, 6-11, 12-17
+  T* rowbuf = Tlo + WAVES * 192;                // [WAVES][32]
   T* hiacc = rowbuf + WAVES * 32;               // [WAVES][maxhi][64]
   __shared__ int lev[32];                       // event of local bit l
   const int prob = chunks[blockIdx.x].x, chunk = chunks[blockIdx.x].y;   // (problem, subset chunk) work list
@@ -1693,10 +1693,14 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
   if (rowvalid) {
     const int klo = kc < 6 ? kc : 6;
     const int nhi = kc - klo;
-    {
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {          // one table per 6-bit part of the subset index
       T v = 1;
-      for (int l = 0; l < klo; ++l) if ((lane >> l) & 1) v *= fvec[lev[l]];
-      Tlo[w * 64 + lane] = v;
+      for (int l = 0; l < 6; ++l) {
+        const int ll = part * 6 + l;
+        if (ll < kc && ((lane >> l) & 1)) v *= fvec[lev[ll]];
+      }
+      Tlo[w * 192 + part * 64 + lane] = v;
     }
     T* ha = hiacc + (long long)w * maxhi * 64;
     for (int l = 0; l < nhi; ++l) ha[l * 64 + lane] = 0;
@@ -1740,9 +1744,10 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
         const long long S0 = S00 + 64 * u;
         if (S0 >= nS) break;
         const uint32_t s = (uint32_t)(S0 + lane);
-        T urate = base;                            // wave-uniform part of the rate
-        for (int l = klo; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
-        const T f = live[u] ? urate * Tlo[w * 64 + (s & 63u)] * (a0[u] + a1[u]) : T(0);
+        T urate = base;                            // wave-uniform part of the rate: two table reads (bits 6-17)
+        urate *= Tlo[w * 192 + 64 + ((S0 >> 6) & 63)] * Tlo[w * 192 + 128 + ((S0 >> 12) & 63)];
+        for (int l = 18; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
+        const T f = live[u] ? urate * Tlo[w * 192 + (s & 63u)] * (a0[u] + a1[u]) : T(0);
         tot += f;
         for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
       }
