@@ -174,6 +174,7 @@ struct Engine : EngineBase {
   DevArr<uint16_t> d_perm;
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
+  bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   // counters
   mmhn_counters cnt{};
@@ -210,6 +211,7 @@ struct Engine : EngineBase {
       const char* sv = std::getenv("MMHN_SOLVER");
       use_jacobi = sv && std::string(sv) == "jacobi";
       if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) psolve_min = std::atoi(pm);
+      if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -601,12 +603,24 @@ struct Engine : EngineBase {
       const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS, tabS.p};
       prep(b.d_dJ.p, nJ, tabJ.p);
       prep(b.d_dS.p, nS, tabS.p);
-      // the substitution solver skips dead tiles: those parts of pi / q_J must hold zeros
-      if (!use_jacobi && pi_owner != b.id) { zero(pi.p, b.vecJ); pi_owner = b.id; }
-      if (!use_jacobi && grad && qJ_owner != b.id) { zero(qJ.p, b.vecJ); qJ_owner = b.id; }
+      const bool per_patient = !use_jacobi && nJ >= psolve_min;
+      // the tile-level substitution solver skips dead tiles and its consumers read them: those parts of pi / q_J
+      // must hold zeros.  The per-patient kernels never let a value of a dead tile into arithmetic (they are only
+      // ever loaded behind a per-state select), so a batch that runs them needs no clearing - which matters when a
+      // cohort takes several batches per evaluation - but leaves the buffers in an unknown state.
+      if (per_patient) {
+        pi_owner = -1;
+        if (grad) qJ_owner = -1;
+        if (poison) {                                  // MMHN_POISON=1 (tests): NaN-fill instead, any leak shows
+          HIPCHECK(hipMemsetAsync(pi.p, 0xFF, (size_t)b.vecJ * sizeof(T), stream));
+          if (grad) HIPCHECK(hipMemsetAsync(qJ.p, 0xFF, (size_t)b.vecJ * sizeof(T), stream));
+        }
+      } else if (!use_jacobi) {
+        if (pi_owner != b.id) { zero(pi.p, b.vecJ); pi_owner = b.id; }
+        if (grad && qJ_owner != b.id) { zero(qJ.p, b.vecJ); qJ_owner = b.id; }
+      }
       // 1-2 joint forward
       if (use_jacobi) launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
-      const bool per_patient = !use_jacobi && nJ >= psolve_min;
       if (per_patient) psolve(false, b, pi.p, 2);
       else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
       // 3 marginal right-hand sides

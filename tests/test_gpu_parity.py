@@ -452,11 +452,16 @@ def test_per_patient_kernels_match_tile_kernels(monkeypatch):
     res = []
     for pmin in ("1", "1000000"):
         monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+        # the per-patient kernels do not clear the solution buffers: NaN-fill them to show that no state of a
+        # skipped (dead) tile ever reaches arithmetic
+        monkeypatch.setenv("MMHN_POISON", "1" if pmin == "1" else "0")
         e = Engine(n)
         e.set_cohort(dat)
         res.append(e.patient_grads(lt, dp, dm))
         e.close()
+    monkeypatch.setenv("MMHN_POISON", "0")
     for x, y in zip(*res):
+        assert np.isfinite(x).all()
         np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
     cref.load()
     lp, g, gp, gm = cref.patients(lt, dp, dm, dat[6:7], with_grad=True)
