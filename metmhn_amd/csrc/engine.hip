@@ -448,6 +448,28 @@ struct Engine : EngineBase {
       batches.push_back(std::move(cur));
       cur = Batch();
     };
+    // a cohort that does not fit the workspace is cut into batches of about equal size (not: full ones and a small
+    // remainder - every batch should be large enough for the per-patient kernels): soft target per batch
+    double soft_target = 0;
+    {
+      double total = 0;
+      for (long long r = 0; r < np; ++r) {
+        const int8_t* row = dat.data() + r * nc;
+        int kp = 0, km = 0, ke = 0;
+        for (int j = 0; j < n; ++j) { kp += row[2 * j] != 0; km += row[2 * j + 1] != 0; ke += row[2 * j] && row[2 * j + 1]; }
+        const int type = row[nc - 1];
+        double el = 0;
+        if (type == 3) {
+          el = (use_jacobi ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
+               (kp + 1) * std::ldexp(1.0, kp) + (km + 1) * std::ldexp(1.0, km) + (ke + 2) * std::ldexp(1.0, ke);
+        } else {
+          el = 4.0 * std::ldexp(1.0, (type == 2 ? km : kp) + 1);
+        }
+        total += el * sizeof(T);
+      }
+      const double nb = std::ceil(total / (double)std::max<size_t>(ws_limit, 1));
+      soft_target = nb > 1 ? total / nb * 1.02 : 0;
+    }
     std::vector<int8_t> st(2 * n + 2);
     for (long long r = 0; r < np; ++r) {
       const int8_t* row = dat.data() + r * nc;
@@ -496,7 +518,8 @@ struct Engine : EngineBase {
       probe.vecS = cur.vecS + (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
       probe.asize = cur.asize + (hasJ ? a_size(dj) : 0);
       const size_t need = (size_t)((use_jacobi ? 4 : 2) * probe.vecJ + 4 * probe.vecS + probe.asize + cur.tabJ + cur.tabS) * sizeof(T);
-      if (!cur.pats.empty() && need > ws_limit) flush();
+      const size_t have = (size_t)((use_jacobi ? 4 : 2) * cur.vecJ + 4 * cur.vecS + cur.asize + cur.tabJ + cur.tabS) * sizeof(T);
+      if (!cur.pats.empty() && (need > ws_limit || (soft_target > 0 && (double)have >= soft_target))) flush();
       if (hasJ) {
         dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
         cur.vecJ += 1ll << dj.k; cur.asize += a_size(dj);
