@@ -229,3 +229,29 @@ def test_load_cohort_roundtrip(tmp_path):
     save_params(str(tmp_path / "p.csv"), np.eye(3), np.zeros(3), np.ones(3), events)
     back = pd.read_csv(tmp_path / "p.csv", index_col=0)
     assert back.shape == (5, 3)
+
+
+def test_bench_line_contract():
+    """The committed bench line of the final tree (profiles/) carries every field the driver's contract names,
+    with the metric of BASELINE.json, and bench.py parses."""
+    import ast
+    import glob
+    import json
+    ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_v*_bench_line.json")),
+                   key=lambda p: int(os.path.basename(p).split("_")[1][1:]))
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == base["metric"] and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
