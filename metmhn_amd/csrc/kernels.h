@@ -1639,7 +1639,7 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 // grid = (work list of (problem, subset chunk), ceil(N / WAVES)); wave w owns event i = blockIdx.y * WAVES + w
 // and strides the subsets S across its lanes; all reductions are wave-level.
-constexpr int GR_CHUNK = 13;                      // subsets per workgroup of k_grad_rows: 2^13
+constexpr int GR_CHUNK = 11;                      // subsets per workgroup of k_grad_rows: 2^11
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ descs,
@@ -1692,7 +1692,8 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
 
   if (rowvalid) {
     const int klo = kc < 6 ? kc : 6;
-    const int nhi = kc - klo;
+    const int kin = kc < GR_CHUNK ? kc : GR_CHUNK;   // subset bits that vary inside this workgroup's chunk
+    const int nhi = kin - klo;
 #pragma unroll
     for (int part = 0; part < 3; ++part) {          // one table per 6-bit part of the subset index
       T v = 1;
@@ -1757,11 +1758,15 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       if (drow) { if (kind != GK_E) rb[n] = total; }
       else { rb[i] = total; if (kind == GK_M) rb[n] = total; }
     }
-    for (int l = 0; l < kc; ++l) {
+    for (int l = 0; l < kin; ++l) {
       const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
       const T m = wave_sum(v);
       if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
     }
+    // bits at or above the chunk size are the same for every subset of the chunk
+    if (lane == 0)
+      for (int l = kin; l < kc; ++l)
+        if (((Sbeg >> l) & 1) && lev[l] != i) rb[lev[l]] = total;
   }
   if (lane < N && rb[lane] != T(0)) atomicAdd(&row[lane], rb[lane]);
 }
