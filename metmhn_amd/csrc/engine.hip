@@ -372,7 +372,7 @@ struct Engine : EngineBase {
 
   // joint solves with many patients in flight: one workgroup per patient, single launch (k_psolve)
   size_t psolve_lds(int maxk) const {
-    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB);
+    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB) + PS_DL * sizeof(T);
   }
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();

@@ -732,6 +732,8 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 // single launch, and the neighbour tiles a tile reads were written moments earlier by the same CU.
 // Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
 // ------------------------------------------------------------------------------------
+constexpr int PS_DL = 272;                      // LDS entries of k_psolve for the per-tile dP / dM slices (2^8 + 2^4)
+
 template <typename T, bool TR>
 __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
                                                    const int* __restrict__ pt_off,
@@ -751,6 +753,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   T* hx = thc + maxk * maxk;
   uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries
   uint16_t* pml = reinterpret_cast<uint16_t*>(pxt + 400);       // popcount order of the tile's states
+  T* dl = reinterpret_cast<T*>(pml + (1 << TB));                // this tile's slices of the dP / dM tables (PS_DL entries)
   const int tid0 = threadIdx.x;
   int tid = tid0;
   const int prob = blockIdx.x;
@@ -786,6 +789,9 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   const T* dP = tab + toff + rate_table_size(k);
   const T* dM = dP + (1ll << __popc(maskP));
   const T* dE = dM + (1ll << __popc(maskM));
+  const int nPin = __popc(cP), nMin = __popc(cM);
+  // a seeded tile needs 2^nPin + 2^nMin consecutive entries of dP / dM: staged in LDS when they fit
+  const bool dl_ok = (1 << nPin) + (1 << nMin) <= PS_DL;
   const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
   JLink<T> Lk;
   if (rhs_mode == 3) Lk = links[prob];
@@ -800,6 +806,17 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     tid = tid0;
     asm volatile("" : "+v"(tid));
     const int wave = tid >> 6, lane = tid & 63;
+    // ---- per tile: the slices of the diagonal tables this tile needs are fetched now and land in LDS behind the
+    // next barrier (no table gather on the critical path after step A)
+    const bool fastt = t == TB && seedb >= t && ((xhi >> seedb) & 1u);
+    T dval = 0;
+    const int dli = tid - 128;
+    if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) {
+      const bool isM = dli >= (1 << nPin);
+      const uint32_t m = isM ? maskM : maskP;
+      const uint32_t hi = pext32(xhi, m & ~tmask) << __popc(m & tmask);
+      dval = isM ? dM[hi | (uint32_t)(dli - (1 << nPin))] : dP[hi | (uint32_t)dli];
+    }
     // ---- per tile: tile-bit factors, compact high parts of the class indices
     if (tid < k) {
       T h = thc[tid * k + tid];
@@ -811,6 +828,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     }
     __syncthreads();
     for (int e = tid; e < k * 64; e += TSB) Utab[e] = Urow[e] * hx[e >> 6];
+    if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) dl[dli] = dval;
     const bool seed_hi = (xhi >> seedb) & 1u;
     const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
     // ---- right-hand side
@@ -918,7 +936,8 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       const uint32_t lo = xl & 63u, hi6 = xl >> 6;
       T v = 1;
       if (plev[j] >= 0) {
-        if ((x >> seedb) & 1u) v = fast_rcp(dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
+        if (fast && dl_ok) v = fast_rcp(dl[pxt[lo] | pxt[64 + hi6]] + dl[(1 << nPin) + (pxt[128 + lo] | pxt[192 + hi6])]);
+        else if ((x >> seedb) & 1u) v = fast_rcp(dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
         else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
       }
       lid[j] = v;
