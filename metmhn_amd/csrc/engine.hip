@@ -372,21 +372,27 @@ struct Engine : EngineBase {
 
   // joint solves with many patients in flight: one workgroup per patient, single launch (k_psolve)
   size_t psolve_lds(int maxk) const {
-    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB) + PS_DL * sizeof(T);
+    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB);
+  }
+  // entries for the per-tile dP / dM slices: whatever is left of half a CU's LDS (two workgroups per CU), at most PS_DL
+  int psolve_dl_cap(int maxk) const {
+    const long long spare = (80 * 1024 - 64) - (long long)psolve_lds(maxk);
+    return (int)std::max<long long>(0, std::min<long long>(PS_DL, spare / (long long)sizeof(T)));
   }
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
     const int mk = std::max(b.maxkJ, 1);
-    const size_t lds = psolve_lds(mk);
+    const int dl_cap = psolve_dl_cap(mk);
+    const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
     timed(bytes, [&]() {
       if (tr)
         hipLaunchKernelGGL((k_psolve<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
-                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p);
+                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
       else
         hipLaunchKernelGGL((k_psolve<T, false>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
-                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p);
+                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
     });
   }
 

@@ -732,7 +732,7 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 // single launch, and the neighbour tiles a tile reads were written moments earlier by the same CU.
 // Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
 // ------------------------------------------------------------------------------------
-constexpr int PS_DL = 272;                      // LDS entries of k_psolve for the per-tile dP / dM slices (2^8 + 2^4)
+constexpr int PS_DL = 528;                      // most LDS entries k_psolve spends on the per-tile dP / dM slices (2^9 + 2^3 ... 2^6 + 2^6)
 
 template <typename T, bool TR>
 __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
                                                    const uint16_t* __restrict__ perm, int maxk,
                                                    const T* __restrict__ tab,
                                                    const JLink<T>* __restrict__ links,
-                                                   const T* __restrict__ qS) {
+                                                   const T* __restrict__ qS, int dl_cap) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   T* hx = thc + maxk * maxk;
   uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries
   uint16_t* pml = reinterpret_cast<uint16_t*>(pxt + 400);       // popcount order of the tile's states
-  T* dl = reinterpret_cast<T*>(pml + (1 << TB));                // this tile's slices of the dP / dM tables (PS_DL entries)
+  T* dl = reinterpret_cast<T*>(pml + (1 << TB));                // this tile's slices of the dP / dM tables (dl_cap entries)
   const int tid0 = threadIdx.x;
   int tid = tid0;
   const int prob = blockIdx.x;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   const T* dE = dM + (1ll << __popc(maskM));
   const int nPin = __popc(cP), nMin = __popc(cM);
   // a seeded tile needs 2^nPin + 2^nMin consecutive entries of dP / dM: staged in LDS when they fit
-  const bool dl_ok = (1 << nPin) + (1 << nMin) <= PS_DL;
+  const bool dl_ok = (1 << nPin) + (1 << nMin) <= dl_cap;   // dl_cap: what the launch could afford (<= PS_DL)
   const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
   JLink<T> Lk;
   if (rhs_mode == 3) Lk = links[prob];
