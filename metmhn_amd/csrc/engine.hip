@@ -578,7 +578,14 @@ struct Engine : EngineBase {
         size_t pos = 0;
         for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
           while (pos < b.mapJ.size() && b.mapJ[pos].x == (int)pj) {
-            if (!dead_tile(b.dJ[pj], (uint32_t)b.mapJ[pos].y)) b.ptiles.push_back((uint16_t)b.mapJ[pos].y);
+            // k_psolve solves the seed = 0 part of a multi-tile space (only its PT == MT states carry values) as a
+            // small lattice over the paired events, so only the seeded tiles are listed; a single-tile space keeps
+            // its one tile
+            const Desc& dj = b.dJ[pj];
+            const uint32_t Ht = (uint32_t)b.mapJ[pos].y;
+            const bool multi = dj.seedbit >= TB && popc(dj.pairP) <= TB;
+            const bool seeded_tile = multi && ((Ht << TB) >> dj.seedbit) & 1u;
+            if (multi ? seeded_tile : !dead_tile(dj, Ht)) b.ptiles.push_back((uint16_t)Ht);
             ++pos;
           }
           b.ptoff.push_back((int)b.ptiles.size());

@@ -477,6 +477,16 @@ __device__ __forceinline__ uint32_t pext32(uint32_t x, uint32_t mask) {
   }
   return out;
 }
+__device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
+  uint32_t out = 0;
+  while (mask) {
+    const uint32_t low = mask & (0u - mask);
+    if (v & 1u) out |= low;
+    v >>= 1;
+    mask ^= low;
+  }
+  return out;
+}
 
 // LIDGV: 1/(D - diag Q) comes from the vector `lidg` (API path, single-tumour spaces);
 // otherwise from the class tables of k_prep (joint spaces with seeding: engine path).
@@ -797,6 +807,49 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   if (rhs_mode == 3) Lk = links[prob];
   __syncthreads();
 
+  // ---- seed = 0 part of a multi-tile space: only the states with PT == MT (both bits of a subset e of the paired
+  // events, nothing else) carry values; they form a lattice over the ke paired events that is solved here in yt,
+  // level by level, one state per thread - before the seeded tiles (which read it through the seeding move) in the
+  // forward solve, after them (it reads their q through the transposed seeding move) in the transposed one.
+  // The other states of the seed = 0 half are never written and never reach arithmetic.
+  const int ke = __popc(pairP);
+  const bool eq_block = seedb >= t && t == TB && ke <= TB;
+  auto solve_eq_block = [&]() {
+    const uint32_t VE = 1u << ke;
+    const T seed_base = thc[seedb * k + seedb];
+    for (int s = 0; s <= ke; ++s) {
+      const int level = TR ? ke - s : s;
+      for (uint32_t e = tid0; e < VE; e += TSB) {
+        if (__popc(e) != level) continue;
+        const uint32_t xp = pdep32(e, pairP);
+        const uint32_t x0 = xp | (xp << 1);
+        T z = (!TR && e == 0) ? e0_scale<T>() : T(0);
+        if (!TR) {
+          for (uint32_t m = xp; m; m &= m - 1) {                 // synchronised event of pair bit b into x0
+            const int bP = __ffs(m) - 1;
+            T r = thc[bP * k + bP];
+            for (uint32_t m2 = xp & ~(1u << bP); m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
+            z += r * yt[pext32(xp & ~(1u << bP), pairP)];
+          }
+        } else {
+          for (uint32_t m = pairP & ~xp; m; m &= m - 1) {        // ... out of x0
+            const int bP = __ffs(m) - 1;
+            T r = thc[bP * k + bP];
+            for (uint32_t m2 = xp; m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
+            z += r * yt[pext32(xp | (1u << bP), pairP)];
+          }
+          T rs = seed_base;                                       // seeding out of x0 (into a seeded tile, already solved)
+          for (uint32_t m2 = xp; m2; m2 &= m2 - 1) rs *= thc[seedb * k + (__ffs(m2) - 1)];
+          z += rs * y[base + (x0 | (1u << seedb))];
+        }
+        const T v = z / dE[e];
+        yt[e] = v;
+        y[base + x0] = v;
+      }
+      __syncthreads();
+    }
+  };
+  if (eq_block && !TR) solve_eq_block();
   uint32_t Hprev = 0xffffffffu;                                 // tile whose solution yt still holds
   for (int it = 0; it < ntile; ++it) {
     const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
@@ -1006,6 +1059,10 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
   }
+  if (eq_block && TR) {
+    __syncthreads();                                             // the seeded tiles' q has landed
+    solve_eq_block();
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1135,16 +1192,6 @@ __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
 // compatible joint states of part `part` (0: PT observed first, 1: MT first): all bits of
 // the observed tumour and the seeding bit set, the other tumour's bits free, ascending.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
-  uint32_t out = 0;
-  while (mask) {
-    const uint32_t low = mask & (0u - mask);
-    if (v & 1u) out |= low;
-    v >>= 1;
-    mask ^= low;
-  }
-  return out;
-}
 
 template <typename T>
 __device__ __forceinline__ T obs_const(const Desc& dj, const Params<T>& P, int part) {
