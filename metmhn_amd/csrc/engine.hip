@@ -94,6 +94,7 @@ struct Batch {
   std::vector<int2> mapX;
   DevArr<int2> d_mapX;
   DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
+  bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   std::vector<int> ptoff;
   std::vector<uint16_t> ptiles;
   DevArr<int> d_ptoff;
@@ -215,8 +216,10 @@ struct Engine : EngineBase {
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -387,12 +390,15 @@ struct Engine : EngineBase {
     const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
     timed(bytes, [&]() {
-      if (tr)
-        hipLaunchKernelGGL((k_psolve<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
-                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
-      else
-        hipLaunchKernelGGL((k_psolve<T, false>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p,
-                           d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
+#define PS_ARGS dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap
+      if (b.all_multi) {
+        if (tr) hipLaunchKernelGGL((k_psolve<T, true, true>), PS_ARGS);
+        else hipLaunchKernelGGL((k_psolve<T, false, true>), PS_ARGS);
+      } else {
+        if (tr) hipLaunchKernelGGL((k_psolve<T, true, false>), PS_ARGS);
+        else hipLaunchKernelGGL((k_psolve<T, false, false>), PS_ARGS);
+      }
+#undef PS_ARGS
     });
   }
 
@@ -569,6 +575,9 @@ struct Engine : EngineBase {
       build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
       b.ptoff.assign(1, 0);
       b.ptiles.clear();
+      b.all_multi = !b.dJ.empty();
+      for (const Desc& dj : b.dJ)
+        if (!(dj.seedbit >= TB && popc(dj.pairP) <= TB)) b.all_multi = false;
       b.mapX.clear();
       for (const int2& m : b.mapJ) {
         const Desc& dj = b.dJ[m.x];

@@ -744,7 +744,9 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 // ------------------------------------------------------------------------------------
 constexpr int PS_DL = 528;                      // most LDS entries k_psolve spends on the per-tile dP / dM slices (2^9 + 2^3 ... 2^6 + 2^6)
 
-template <typename T, bool TR>
+// MULTI: every problem of the launch is a multi-tile space whose seed = 0 part takes the lattice solve, so every
+// listed tile is a full seeded one and the per-state (generic) paths are compiled out
+template <typename T, bool TR, bool MULTI>
 __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
                                                    const int* __restrict__ pt_off,
                                                    const uint16_t* __restrict__ ptiles,
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     const int wave = tid >> 6, lane = tid & 63;
     // ---- per tile: the slices of the diagonal tables this tile needs are fetched now and land in LDS behind the
     // next barrier (no table gather on the critical path after step A)
-    const bool fastt = t == TB && seedb >= t && ((xhi >> seedb) & 1u);
+    const bool fastt = MULTI || (t == TB && seedb >= t && ((xhi >> seedb) & 1u));
     T dval = 0;
     const int dli = tid - 128;
     if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) {
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       }
     }
     __syncthreads();                                   // Utab complete; the previous tile's stores have landed
-    const bool fast = t == TB && seedb >= t && seed_hi;
+    const bool fast = MULTI || (t == TB && seedb >= t && seed_hi);
     // ---- step A: transitions that cross the tile boundary
     // one move (bit b; kind 1 = the pair move of P bit b) with every condition evaluated per state
     auto gen_move = [&](int b, int kind) {
@@ -962,7 +964,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
         for (int j = 0; j < NJ; ++j) acc[j] += Lb * Utab[b * 64 + wave + NW * j] * nf[j];
       }
       if (!TR && seed_move_possible(lone, pairP, xhi, tmask)) gen_move(seedb, 0);
-    } else {
+    } else if constexpr (!MULTI) {
       for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
         gen_move(b, 0);
         if ((pairP >> b) & 1u) gen_move(b, 1);
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
             asm volatile("" ::: "memory");                 // all nine LDS reads in flight before the first use
             z += lv[0] * uv[0] * yv[0] + lv[1] * uv[1] * yv[1] + lv[2] * uv[2] * yv[2];
           }
-        } else {
+        } else if constexpr (!MULTI) {
           const uint32_t x = xhi | xl;
           const bool ss = (x >> seedb) & 1u;
           const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
