@@ -772,7 +772,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = sgpr(d.k);
-  const int t = k < TB ? k : TB;
+  const int t = MULTI ? TB : (k < TB ? k : TB);            // MULTI: full tiles only, the bounds below fold away
   const uint32_t nelem = 1u << t, tmask = nelem - 1;
   const long long base = sgpr64(d.off);
   const long long toff = sgpr64(d.toff);
