@@ -1009,10 +1009,11 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
         T z = yt[xl];
         uint32_t todo = TR ? (~xl & tmask) : xl;
         if (fast) {
+          constexpr int TPT = (MULTI && !TR) ? 4 : 3;      // terms per trip (what the register budget allows)
           while (todo) {
-            T lv[3], uv[3], yv[3];
+            T lv[TPT], uv[TPT], yv[TPT];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < TPT; ++u) {
               const bool on = todo != 0;
               const int b = on ? __ffs(todo) - 1 : 0;
               todo &= todo - 1;
@@ -1021,8 +1022,11 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
               uv[u] = Utab[b * 64 + ro];
               yv[u] = yt[yi];
             }
-            asm volatile("" ::: "memory");                 // all nine LDS reads in flight before the first use
-            z += lv[0] * uv[0] * yv[0] + lv[1] * uv[1] * yv[1] + lv[2] * uv[2] * yv[2];
+            asm volatile("" ::: "memory");                 // all LDS reads of the trip in flight before the first use
+            T zz = lv[0] * uv[0] * yv[0];
+#pragma unroll
+            for (int u = 1; u < TPT; ++u) zz += lv[u] * uv[u] * yv[u];
+            z += zz;
           }
         } else if constexpr (!MULTI) {
           const uint32_t x = xhi | xl;
