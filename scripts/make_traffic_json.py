@@ -30,7 +30,7 @@ for name, tag, kern in (("kronvec", "kv", "k_sweep<double, false>"), ("kronvec_T
 P = 2048
 ef, ew = per_launch("eval_f", "FETCH_SIZE"), per_launch("eval_w", "WRITE_SIZE")
 ek = {"_comment": "per launch over 2048 n=20 full-k patients; bytes_per_patient = (2 x FETCH_SIZE + WRITE_SIZE) / patients"}
-for name, kern in (("k_psolve_fwd", "k_psolve<double, false>"), ("k_psolve_adj", "k_psolve<double, true>"), ("k_pclass", "k_pclass<double>")):
+for name, kern in (("k_psolve_fwd", "k_psolve<double, false, true>"), ("k_psolve_adj", "k_psolve<double, true, true>"), ("k_pclass", "k_pclass<double>")):
     ek[name] = {"patients": P, "fetch_kb_reported": ef[kern], "write_kb": ew[kern],
                 "bytes_per_patient": (2 * ef[kern] + ew[kern]) * 1024 / P}
 out["eval_kernels"] = ek
