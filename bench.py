@@ -4,22 +4,28 @@
 One "step" = one full-cohort evaluation of regularized_optimization.score_and_grad_reg
 (value + full gradient, perc_met = 0.5, symmetric_penal, lambda = 1e-3): parameter upload,
 every kernel of the likelihood/gradient pipeline, the RCCL all-reduce of the partial sums
-when N > 1, the download and the host-side penalty.  Workload at every N: BASELINE.json
-configs[2] per GPU - synthetic "full-k" cohort, n = 20 events, 5 000 paired patients per
-GPU (k = 20 -> 2^20-state vectors, 8 MiB fp64 each), weak scaling; the cohort is resident
-in HBM (uploaded and laid out before the timed region).
+when N > 1 (inside the library, on the engine's stream), the download and the host-side
+penalty.  Workload at every N: BASELINE.json configs[2] per GPU - synthetic "full-k" cohort,
+n = 20 events, 5 000 paired patients per GPU (k = 20 -> 2^20-state vectors, 8 MiB fp64
+each), weak scaling; the cohort is resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py                      # 1 GPU
+    python bench.py --gpus N             # starts N ranks itself (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # the driver's form
 
 Rank 0 prints ONE JSON line.  `value` counts 5 000-patient cohort evaluations per second
-over all ranks (N GPUs evaluate an N x 5 000 patient cohort per step).
+over all ranks (N GPUs evaluate an N x 5 000 patient cohort per step).  `roofline` is the
+dominant kernel OF THE TIMED REGION (k_psolve, forward instantiation), timed with HIP events
+on the engine's stream inside that region; every figure in the line can be recomputed from
+`alg_bytes_per_launch`, `avg_launch_ms` and the CSVs under profiles/.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,18 +34,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=20, help="events (k = n active bits per patient)")
     ap.add_argument("--patients", type=int, default=5000, help="patients per GPU")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="patients timed on the CPU baseline (-1: one per core)")
+    ap.add_argument("--workload", default="full-k", choices=["full-k", "luad"],
+                    help="full-k: BASELINE configs[2]; luad: the LUAD-reduced cohort of configs[0] (small-k regime)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="patients timed on the reference-structure CPU baseline (-1: two per core)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kronvec / stream / small-cohort legs")
     ap.add_argument("--kronvec-batch", type=int, default=64)
     return ap.parse_args()
 
@@ -86,62 +97,98 @@ dat = synthetic.full_k_cohort(n, {patients}, seed=2000 + n)
 cref.load_fast()
 cref.fast_patients(lt, dp, dm, dat[:cores], threads=cores)
 t0 = time.perf_counter()
-cref.fast_patients(lt, dp, dm, dat[:sample], threads=cores)
-print(json.dumps(dict(dt=time.perf_counter() - t0)))
+res = cref.fast_patients(lt, dp, dm, dat[:sample], threads=cores)
+dt = time.perf_counter() - t0
+np.savez({out!r}, lp=res[0], g=res[1], gp=res[2], gm=res[3])
+print(json.dumps(dict(dt=dt)))
 """
+
+
+def _cpu_env(cores):
+    return dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0", OMP_PROC_BIND="false")
 
 
 def cpu_baseline_optimised(n, patients, budget_s=300):
     """oracle/metmhn_fast.c: the same mathematics as the GPU engine (closed-form rates, substitution solves,
-    class-marginal gradients) on the host cores, one patient per core at a time ("so the speed-up
-    is not flattered by a deliberately slow baseline").  Sample: 32 patients per core of the same cohort."""
-    import subprocess
+    class-marginal gradients) on the host cores ("so the speed-up is not flattered by a deliberately slow
+    baseline").  Sample: 32 patients per core of the same cohort; its per-patient results are handed back so that
+    the engine's evaluation of the bench cohort is CHECKED against them."""
     cores = host_cores()
     sample = min(patients, 32 * cores)
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0", OMP_PROC_BIND="false")
-    code = _CPU_FAST_SCRIPT.format(root=ROOT, n=n, sample=sample, cores=cores, patients=patients)
+    out = os.path.join(tempfile.gettempdir(), f"mmhn_bench_cpu_{os.getpid()}.npz")
+    code = _CPU_FAST_SCRIPT.format(root=ROOT, n=n, sample=sample, cores=cores, patients=patients, out=out)
     try:
-        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=budget_s)
+        res = subprocess.run([sys.executable, "-c", code], env=_cpu_env(cores), capture_output=True, text=True, timeout=budget_s)
         dt = json.loads(res.stdout.strip().splitlines()[-1])["dt"]
+        ref = dict(np.load(out))
+        os.unlink(out)
     except Exception as exc:
         return dict(value=None, unit="evals/s", cores=cores, kind="port",
-                    sample=f"optimised CPU variant did not finish within {budget_s} s ({type(exc).__name__})")
+                    sample=f"optimised CPU variant did not finish within {budget_s} s ({type(exc).__name__})"), None
     return dict(value=(sample / dt) / 5000.0, unit="evals/s", cores=cores, kind="port",
                 sample=f"{sample} of the {patients} patients of the same n={n} cohort (log-lik + gradient, gather "
                        f"formulation with substitution solves = the engine's own algorithm in C, OpenMP over patients "
-                       f"on {cores} threads), {dt:.2f} s wall, extrapolated linearly to 5000 patients")
+                       f"on {cores} threads), {dt:.2f} s wall, extrapolated linearly to 5000 patients"), ref
 
 
-def cpu_baseline(n, patients, sample, budget_s=300):
-    """C restatement of the reference pass structure (oracle/metmhn_ref.c) on the host cores.
-
-    Runs in a fresh process (own OpenMP runtime, passive waits, thread count = CPU share) on a bounded
-    sample of the same cohort: one patient per core, OpenMP over patients."""
-    import subprocess
+def cpu_baseline(n, patients, sample, budget_s=600):
+    """C restatement of the reference pass structure (oracle/metmhn_ref.c) on the host cores, in a fresh process
+    (own OpenMP runtime, passive waits, thread count = CPU share), on a bounded sample of the same cohort: two
+    patients per core, OpenMP over patients."""
     cores = host_cores()
     if sample < 0:
-        sample = cores
-    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_WAIT_POLICY="PASSIVE", GOMP_SPINCOUNT="0",
-               OMP_PROC_BIND="false")
+        sample = 2 * cores
     code = _CPU_SCRIPT.format(root=ROOT, n=n, sample=sample, cores=cores, patients=patients)
     try:
-        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=budget_s)
+        res = subprocess.run([sys.executable, "-c", code], env=_cpu_env(cores), capture_output=True, text=True, timeout=budget_s)
         dt = json.loads(res.stdout.strip().splitlines()[-1])["dt"]
     except Exception as exc:                      # report the failure instead of hanging the bench
         return dict(value=None, unit="evals/s", cores=cores, kind="port",
                     sample=f"CPU baseline did not finish within {budget_s} s ({type(exc).__name__})")
     return dict(value=(sample / dt) / 5000.0, unit="evals/s", cores=cores, kind="port",
-                sample=f"{sample} of the {patients} patients of the same n={n} cohort (log-lik + gradient, "
-                       f"reference pass structure, OpenMP over patients on {cores} threads), "
+                sample=f"{sample} of the {patients} patients of the same n={n} cohort ({sample // cores} per core; "
+                       f"log-lik + gradient, reference pass structure, OpenMP over patients on {cores} threads), "
                        f"{dt:.1f} s wall, extrapolated linearly to 5000 patients")
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: this parent never touches the GPU; it starts the N ranks as a
+    child `torch.distributed.run` (127.0.0.1 rendezvous, free port) and relays rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def luad_cohort(n_default=20):
+    """The LUAD-reduced cohort (4 852 x 43 int8, tests/golden/luad_indep.npz: data derived from the reference's
+    data/luad CSVs by tests/tools/make_golden_luad.py) and the `indep` start; a synthetic cohort of the same
+    composition if the fixture is absent."""
+    path = os.path.join(ROOT, "tests", "golden", "luad_indep.npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        return g["dat"], g["indep_theta"], g["indep_dp"], g["indep_dm"], float(g["perc_met"]), "LUAD-reduced (tests/golden/luad_indep.npz)"
+    from metmhn_amd import synthetic
+    lt, dp, dm = synthetic.random_params(n_default)
+    return synthetic.mixed_cohort(n_default, 4852, seed=3), lt, dp, dm, 0.2, "synthetic mixed cohort, 4 852 rows (fixture absent)"
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a))
     T0 = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     import torch
     import torch.distributed as dist
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
@@ -150,26 +197,37 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    from metmhn_amd import synthetic, distributed as D
+    from metmhn_amd import synthetic
     import metmhn_amd.regularized_optimization as ro
     ro.configure(device=local, dtype=a.dtype, shard=True)
-
-    n, N = a.n, a.n + 1
-    lt, dp, dm = synthetic.random_params(n)
-    # global cohort = `world` blocks of `patients` rows; the engine of rank r keeps the LPT shard r
-    dat = np.vstack([synthetic.full_k_cohort(n, a.patients, seed=2000 + n + 7919 * r) for r in range(world)])
-    params = np.concatenate((lt.flatten(), dp, dm))
 
     def note(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    if a.workload == "luad":
+        dat, lt, dp, dm, perc_met, wl_name = luad_cohort()
+        n = (dat.shape[1] - 3) // 2
+        dat = np.vstack([dat] * world)
+        unit_rows = dat.shape[0] // world
+    else:
+        n = a.n
+        lt, dp, dm = synthetic.random_params(n)
+        # global cohort = `world` blocks of `patients` rows; the engine of rank r keeps the LPT shard r
+        dat = np.vstack([synthetic.full_k_cohort(n, a.patients, seed=2000 + n + 7919 * r) for r in range(world)])
+        perc_met, unit_rows = 0.5, a.patients
+        wl_name = (f"synthetic full-k cohort, n={n} events, {a.patients} paired patients per GPU, 2^{n}-state vectors, "
+                   f"{a.dtype} (BASELINE.json configs[2] per GPU)")
+    N = n + 1
+    params = np.concatenate((np.asarray(lt).flatten(), dp, dm))
+    esz = 8 if a.dtype == "f64" else 4
+
     note("building cohort layout")
     eng = ro._engine_for(dat)                    # uploads and lays out this rank's shard (outside the timed region)
-    note("cohort resident")
+    note(f"cohort resident (in-library RCCL communicator: {bool(getattr(eng, '_device_comm', False))})")
 
     def step():
-        return ro.score_and_grad_reg(params, dat, 0.5, ro.symmetric_penal, 1e-3)
+        return ro.score_and_grad_reg(params, dat, perc_met, ro.symmetric_penal, 1e-3)
 
     def fence():
         if use_dist:
@@ -191,75 +249,145 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     cnt = eng.counters()
-    note(f"timed region done: {dt:.2f} s for {a.steps} steps")
+    note(f"timed region done: {dt:.3f} s for {a.steps} steps")
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        value = world * (a.patients / 5000.0) * a.steps / dt
-        # ---- metric 2 / roofline unit of SURVEY 8(d): batched kronvec Q_off p on 64 resident 2^k vectors
-        # (working set 1 GiB > 256 MiB Infinity Cache), HIP events on the engine's stream around 20 launches
-        st = dat[0, :2 * n + 1]
-        kb = a.kronvec_batch
-        V = (2 ** int(st.sum())) * (8 if a.dtype == "f64" else 4)
-        traffic = {}
+        unit = 5000.0 if a.workload == "full-k" else float(unit_rows)
+        value = world * (unit_rows / unit) * a.steps / dt
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            traffic = json.load(open(TRAFFIC_FILE))
         except Exception:
-            pass
-        kv = {}
-        for name, tr, jac, mult in (("kronvec", 0, 0, 2), ("kronvec_T", 1, 0, 2), ("jacobi_step", 0, 1, 4)):
-            ms = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac)
-            kv[name] = {"ms_per_launch": ms, "alg_GBps": mult * V * kb / ms / 1e6,
-                        "frac_of_peak": mult * V * kb / ms / 1e6 / HBM_PEAK_GBPS, "batch": kb,
-                        "alg_bytes_per_launch": mult * V * kb}
-        tr_kv = traffic.get("kronvec", {}) if (n == 20 and kb == 64 and a.dtype == "f64") else {}
-        ek = traffic.get("eval_kernels", {}) if (n == 20 and a.dtype == "f64") else {}
-        solve_traffic = (ek["k_psolve_fwd"]["bytes_per_patient"] + ek["k_psolve_adj"]["bytes_per_patient"]) if ek else None
-        kern_ms = cnt["sweep_ms"] / max(cnt["sweep_launches"], 1)
-        achieved = cnt["sweep_alg_bytes"] / max(cnt["sweep_ms"], 1e-9) / 1e6      # GB/s
-        b_pat = (7 * (n + 1) + 4) * (2 ** n) * (8 if a.dtype == "f64" else 4)      # Jacobi-formulation floor per patient
+            traffic = {}
+        traffic_ok = a.workload == "full-k" and n == 20 and a.dtype == "f64" and a.patients == 5000
+        ek = traffic.get("eval_kernels", {}) if traffic_ok else {}
+
+        # ---- measured stream bandwidth of this box (next to the nominal 8 TB/s)
+        stream = {}
+        if not a.no_extras:
+            stream = {"copy_GBps": eng.bench_stream(1 << 30, 10, "copy"), "triad_GBps": eng.bench_stream(1 << 30, 10, "triad"),
+                      "what": "16 B/lane copy b=a / triad a=b+s*c over 1 GiB arrays, HIP events, bytes moved / time"}
+            note("stream leg done")
+
+        # ---- per-kernel roofline of the timed region (HIP events on the engine's stream around every launch)
+        def kern(name, label, alg_note):
+            c = cnt[name]
+            if c["launches"] == 0:
+                return None
+            avg_ms = c["ms"] / c["launches"]
+            per_launch = c["alg_bytes"] / c["launches"]
+            ach = per_launch / avg_ms / 1e6
+            tr = ek.get(name, {})
+            o = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                 "traffic": tr.get("bytes_per_launch"), "kernel": label, "launches": int(c["launches"]),
+                 "avg_launch_ms": avg_ms, "alg_bytes_per_launch": per_launch, "alg_bytes": alg_note,
+                 "ms_per_step": c["ms"] / a.steps}
+            if tr:
+                o["traffic_source"] = ("recorded offline: profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in "
+                                       "separate passes over this same command; 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)")
+                o["traffic_over_alg"] = tr["bytes_per_launch"] / per_launch
+                o["traffic_GBps"] = tr["bytes_per_launch"] / avg_ms / 1e6
+            if stream:
+                o["frac_of_measured_copy"] = ach / stream["copy_GBps"]
+            return o
+
+        T = "double" if a.dtype == "f64" else "float"
+        rf_fwd = kern("psolve_fwd", f"k_psolve<{T},false,*> (forward substitution solve, one workgroup per patient)",
+                      "solution written once: live (seeded) tiles x 2^12 x sizeof(dtype)")
+        rf_adj = kern("psolve_adj", f"k_psolve<{T},true,*> (adjoint substitution solve)", "solution written once")
+        rf_marg = kern("pclass", f"k_pclass<{T}> (class marginals of pi (x) q)", "pi and q_J read once (live tiles)")
+        rf_other = kern("other_solve", "k_tsolve / k_sweep (level-by-level solves of the marginal single-tumour problems)",
+                        "per tile: solution written once (+ dense rhs / lidg vector reads)")
+        live_bytes = (cnt["psolve_fwd"]["alg_bytes"] / max(cnt["psolve_fwd"]["launches"], 1)) if rf_fwd else None
+        dominant = rf_fwd or rf_other or {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
         out = {
             "metric": "full-cohort log-lik+grad evals/sec at n=20 events; kronvec HBM GB/s",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"synthetic full-k cohort, n={n} events, {a.patients} paired patients per GPU, "
-                                   f"2^{n}-state vectors, {a.dtype} (BASELINE.json configs[2] per GPU)",
-                       "patients_total": world * a.patients, "perc_met": 0.5, "penalty": "symmetric_penal 1e-3",
-                       "parallelism": f"patient-shard x{world}, one all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval",
+            "dtype": a.dtype, "data": "synthetic" if a.workload == "full-k" else "LUAD-reduced genotypes (derived fixture), indep() parameters",
+            "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
+                       "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval "
+                                      f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
                        "solver": os.environ.get("MMHN_SOLVER", "substitution (k_psolve per patient, k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
-            # kronvec kernel k_sweep<T,false>: the unit of SURVEY 8(d) (B_kv = 2 * 2^k * s per vector), measured live above
-            "roofline": {"bound": "hbm", "achieved": kv["kronvec"]["alg_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": kv["kronvec"]["frac_of_peak"], "traffic": tr_kv.get("bytes_per_launch"),
-                         "kernel": "k_sweep<double,false> (batched kronvec Q_off p)", "launches": 20,
-                         "avg_launch_ms": kv["kronvec"]["ms_per_launch"],
-                         "alg_bytes_per_launch": kv["kronvec"]["alg_bytes_per_launch"],
-                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE)" if tr_kv else None},
-            # dominant kernels of the evaluation itself: the two substitution solves (one workgroup per patient).
-            # Algorithmic bytes = the solution written once; the PMC traffic is ~5x that - every tile re-reads the
-            # solved neighbour tiles it depends on - and both k_psolve and k_pclass run at the ~3.7 TB/s this chip
-            # sustains for such mixed read/write streams (profiles/README.md)
-            "roofline_solver": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": achieved / HBM_PEAK_GBPS,
-                                "traffic": (solve_traffic * a.patients / 2.0) if solve_traffic else None,
-                                "traffic_GBps": (solve_traffic * a.patients * a.steps / (cnt["sweep_ms"] * 1e6)) if solve_traffic else None,
-                                "kernel": "k_psolve<double,false|true> (forward + adjoint substitution solve; the few-launch "
-                                          "k_tsolve solves of the marginal problems are in the same counters), HIP events "
-                                          "inside the timed region",
-                                "launches": int(cnt["sweep_launches"]), "avg_launch_ms": kern_ms,
-                                "solve_ms_per_eval": cnt["sweep_ms"] / a.steps,
-                                "alg_bytes_per_launch": cnt["sweep_alg_bytes"] / max(cnt["sweep_launches"], 1),
-                                "traffic_source": "profiles/r1_traffic.json eval_kernels (rocprofv3 --pmc, 2 x FETCH_SIZE + WRITE_SIZE, per patient, mean of the two solves)" if solve_traffic else None},
-            # the same evaluations priced at the reference formulation's floor B_pat = [7(k+1)+4] 2^k s per patient
-            "eval_vs_jacobi_floor": {"B_pat_bytes": b_pat, "equivalent_GBps": b_pat * a.patients * world * a.steps / dt / 1e9,
-                                     "note": "substitution solves move less than this floor; >8000 means faster than any Jacobi-sweep implementation could be on this chip"},
+            # dominant kernel of the timed step
+            "roofline": dominant,
+            "roofline_adjoint": rf_adj, "roofline_marginals": rf_marg, "roofline_other_solves": rf_other,
+            "measured_stream": stream or None,
         }
-        out["kronvec"] = kv
-        note("kronvec leg done")
-        if world == 1 and not a.no_cpu:
+        if live_bytes:
+            # compulsory traffic of the substitution formulation per evaluation: write pi and q_J once, read each once
+            floor = 4.0 * live_bytes
+            out["eval_floor"] = {"bytes_per_step": floor, "floor_ms_at_peak": floor / HBM_PEAK_GBPS / 1e6,
+                                 "frac_of_floor": floor / HBM_PEAK_GBPS / 1e6 / ms_per_step,
+                                 "note": "4 x live bytes (write pi, q_J; read each once) / 8 TB/s over the measured step"}
+            if stream:
+                out["eval_floor"]["frac_of_floor_measured_copy"] = floor / stream["copy_GBps"] / 1e6 / ms_per_step
+        if ek:
+            tot = sum(v.get("bytes_per_launch", 0) * v.get("launches_per_step", 1) for v in ek.values())
+            out["eval_traffic"] = {"bytes_per_step": tot, "over_floor": tot / (4.0 * live_bytes) if live_bytes else None,
+                                   "source": "recorded offline: profiles/r2_traffic.json"}
+
+        if not a.no_extras and a.workload == "full-k":
+            # ---- metric 2: batched kronvec Q_off p on `kb` resident 2^k vectors (working set > Infinity
+            # Cache), HIP events on the engine's stream around 20 launches; B_kv = 2 * 2^k * s per vector
+            st = dat[0, :2 * n + 1]
+            kb = a.kronvec_batch
+            V = (2 ** int(st.sum())) * esz
+            tkv = traffic.get("kronvec", {}) if (n == 20 and kb == 64 and a.dtype == "f64") else {}
+            kv = {}
+            for name, tr, jac, mult in (("kronvec", 0, 0, 2), ("kronvec_T", 1, 0, 2), ("jacobi_step", 0, 1, 4)):
+                ms = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac)
+                alg = mult * V * kb
+                kv[name] = {"ms_per_launch": ms, "alg_GBps": alg / ms / 1e6, "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBPS,
+                            "batch": kb, "alg_bytes_per_launch": alg}
+                if name in tkv:
+                    kv[name]["traffic"] = tkv[name]["bytes_per_launch"]
+                    kv[name]["moved_GBps"] = tkv[name]["bytes_per_launch"] / ms / 1e6
+                    kv[name]["frac_of_peak_moved"] = tkv[name]["bytes_per_launch"] / ms / 1e6 / HBM_PEAK_GBPS
+                    kv[name]["traffic_source"] = "recorded offline: profiles/r2_traffic.json"
+                if stream:
+                    kv[name]["frac_of_measured_copy"] = alg / ms / 1e6 / stream["copy_GBps"]
+            out["kronvec"] = kv
+            note("kronvec leg done")
+            # ---- small-k regime (BASELINE configs[0]): one LUAD-sized evaluation, launch-bound
+            try:
+                sdat, slt, sdp, sdm, spm, sname = luad_cohort()
+                sp = np.concatenate((np.asarray(slt).flatten(), sdp, sdm))
+                ro.score_and_grad_reg(sp, sdat, spm, ro.symmetric_penal, 1e-3)
+                ts = []
+                for _ in range(10):
+                    t1 = time.perf_counter()
+                    ro.score_and_grad_reg(sp, sdat, spm, ro.symmetric_penal, 1e-3)
+                    ts.append(time.perf_counter() - t1)
+                tsc = []
+                for _ in range(10):
+                    t1 = time.perf_counter()
+                    ro.score_reg(sp, sdat, spm, ro.symmetric_penal, 1e-3)
+                    tsc.append(time.perf_counter() - t1)
+                out["small_cohort"] = {"workload": sname, "rows": int(sdat.shape[0]), "ms_per_eval_with_grad": float(np.median(ts) * 1e3),
+                                       "ms_per_eval_score_only": float(np.median(tsc) * 1e3)}
+            except Exception as exc:
+                out["small_cohort"] = {"error": repr(exc)}
+            note("small-cohort leg done")
+        if world == 1 and not a.no_cpu and a.workload == "full-k":
             out["cpu_baseline"] = cpu_baseline(n, a.patients, a.cpu_sample)
-            out["cpu_baseline_optimised"] = cpu_baseline_optimised(n, a.patients)
+            note("cpu baseline (reference structure) done")
+            opt, ref = cpu_baseline_optimised(n, a.patients)
+            out["cpu_baseline_optimised"] = opt
+            if ref is not None:
+                # parity of the timed workload itself: the engine's per-patient results for the rows the CPU just did
+                m = ref["lp"].shape[0]
+                lp, g, gp, gm = eng.patient_grads(lt, dp, dm)
+                def rel(x, y):
+                    return float(np.max(np.abs(x - y)) / max(np.max(np.abs(y)), 1e-300))
+                errs = {"lp": rel(lp[:m], ref["lp"]), "d_theta": rel(g[:m], ref["g"]), "d_dp": rel(gp[:m], ref["gp"]),
+                        "d_dm": rel(gm[:m], ref["gm"])}
+                out["checked_patients"] = int(m)
+                out["max_rel_err"] = max(errs.values())
+                out["check"] = {"against": "oracle/metmhn_fast.c on the host (fp64), first rows of the bench cohort", "errors": errs,
+                                "tolerance": 1e-6 if a.dtype == "f64" else 1e-2}
+            note("optimised CPU baseline + cross-check done")
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

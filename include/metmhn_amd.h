@@ -73,6 +73,8 @@ int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log
  * mmhn_resolvent      <-> likelihood.R_i_inv_vec (:231-262)   (D_p + D_m - Q)^-1 x
  * mmhn_x_partial_Q_y  <-> likelihood.x_partial_Q_y (:163-201) G[N][N]
  * mmhn_x_partial_D_y  <-> likelihood.x_partial_D_y (:204-228) (takes log_d_p, log_d_m in THAT order)
+ * mmhn_partial_diag_scal <-> kronvec.partial_diag_scal_p / _m (:605-644, :674-710): (dD/dlog d[i]) * p,
+ *                         which: 0 = p, 1 = m; i in [0, n_mut] (n_mut = the seeding entry)
  */
 int mmhn_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
                  double* y, int diag, int transpose);
@@ -88,11 +90,19 @@ int mmhn_x_partial_Q_y(mmhn_handle h, const double* log_theta, const int8_t* sta
 int mmhn_x_partial_D_y(mmhn_handle h, const double* log_d_p, const double* log_d_m,
                        const int8_t* state, const double* x, const double* y, double* d_dp,
                        double* d_dm);
+int mmhn_partial_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, const double* p,
+                           int i, int which, double* y);
 
 /* ---- single-tumour primitives (metmhn/jx/vanilla.py); state has n+1 entries ---------
  * mmhn_v_kronvec       <-> vanilla.kronvec        (:78-106)
  * mmhn_v_resolvent     <-> vanilla.R_inv_vec      (:269-305)  d_rates == NULL means 1
  * mmhn_v_x_partial_Q_y <-> vanilla.x_partial_Q_y  (:328-393)  G[N][N], d_diag[N]
+ * mmhn_v_kron_diag     <-> vanilla.kron_diag      (:247-260)  diag(Q) * diag  (diag == NULL means ones)
+ * mmhn_v_scal_d_pt     <-> vanilla.scal_d_pt      (:125-142)  observation rates of an MT-only datapoint:
+ *                          out_p = [seeding clear] prod d_p * vec, out_m = [seeding set] d_m[n] prod d_m * vec
+ * mmhn_v_d_scal_d_pt   <-> vanilla.d_scal_d_pt    (:144-187)  their derivatives w.r.t. log d[i]
+ * mmhn_v_x_partial_D_y <-> vanilla.x_partial_D_y  (:190-203)  (d_dp[N], d_dm[N]); argument order (log_d_p, log_d_m)
+ * The three scal_d_pt functions need state[n_mut] == 1 (the reference applies a 2-state factor to the seeding bit).
  */
 int mmhn_v_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
                    double* y, int diag, int transpose);
@@ -100,6 +110,26 @@ int mmhn_v_resolvent(mmhn_handle h, const double* log_theta, const int8_t* state
                      const double* d_rates, const double* x, double* y, int transpose);
 int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* log_theta, const int8_t* state,
                          const double* x, const double* y, double* G, double* d_diag);
+int mmhn_v_kron_diag(mmhn_handle h, const double* log_theta, const int8_t* state, const double* diag,
+                     double* out);
+int mmhn_v_scal_d_pt(mmhn_handle h, const double* log_d_p, const double* log_d_m, const int8_t* state,
+                     const double* vec, double* out_p, double* out_m);
+int mmhn_v_d_scal_d_pt(mmhn_handle h, const double* log_d_p, const double* log_d_m, const int8_t* state,
+                       const double* vec, int i, double* out_p, double* out_m);
+int mmhn_v_x_partial_D_y(mmhn_handle h, const double* log_d_p, const double* log_d_m,
+                         const int8_t* state, const double* x, const double* y, double* d_dp,
+                         double* d_dm);
+
+/* ---- patient shards on several GPUs (one process and one engine per GPU) ----------------
+ * The reference is single-process; its cohort sum (regularized_optimization.py:256-266) is what shards.
+ * Rank 0 draws an id (mmhn_comm_unique_id, 128 bytes) and hands it to every rank by any host channel; after
+ * mmhn_comm_init every mmhn_cohort_sums / mmhn_score / mmhn_score_and_grad of the handle returns the sums over
+ * ALL ranks' cohorts: one RCCL all-reduce of the 4 + 2 N^2 + 3 N doubles on the engine's stream per evaluation,
+ * no host staging.  Every rank must make the same calls in the same order (collective semantics).
+ */
+int mmhn_comm_unique_id(void* id128);
+int mmhn_comm_init(mmhn_handle h, const void* id128, int rank, int n_ranks);
+int mmhn_comm_destroy(mmhn_handle h);
 
 /* ---- simulation ---------------------------------------------------------
  * mmhn_simulate: Gillespie sampler of the joint PT/MT process, one trajectory per thread; replaces
@@ -116,18 +146,31 @@ int mmhn_simulate(mmhn_handle h, const double* log_theta, const double* pt_d_ef,
  * mmhn_bench_kronvec: `batch` resident copies of a 2^k vector, `iters` back-to-back
  * launches of the batched Q_off p kernel (or the fused Jacobi step if jacobi != 0) timed
  * with HIP events on the engine's stream; returns the average launch duration in ms.
- * mmhn_get_counters: cumulative figures since mmhn_reset_counters (events recorded on the
- * engine's stream around every launch of the solve-sweep kernel).
+ * mmhn_get_counters: cumulative figures since mmhn_reset_counters, per class of dominant kernel (events recorded
+ * on the engine's stream around every launch).
  */
+enum { MMHN_K_OTHER_SOLVE = 0,  /* per-tile solves / Jacobi sweeps (k_tsolve, k_sweep): marginal problems, small batches */
+       MMHN_K_PSOLVE_FWD = 1,   /* k_psolve forward: one workgroup per patient, (D - Q) pi = e_0 */
+       MMHN_K_PSOLVE_ADJ = 2,   /* k_psolve adjoint: (D - Q)^T q = rhs */
+       MMHN_K_PCLASS = 3,       /* k_pclass: class marginals of pi (x) q */
+       MMHN_K_COUNT = 4 };
 typedef struct {
-  double sweep_ms;        /* total duration of solve-sweep kernel launches */
-  int64_t sweep_launches; /* number of those launches */
-  double sweep_alg_bytes; /* algorithmic bytes they moved (4 * 2^k * sizeof(dtype) per state vector and sweep) */
-  double eval_ms;         /* host wall time spent inside mmhn_cohort_sums */
+  double ms;         /* total duration of the launches (HIP events on the engine's stream) */
+  int64_t launches;
+  double alg_bytes;  /* algorithmic bytes of those launches: solves = the solution written once (live tiles),
+                        marginals = pi and q read once, Jacobi sweep = 4 * 2^k * sizeof(dtype) per vector */
+} mmhn_kernel_counter;
+typedef struct {
+  mmhn_kernel_counter kernel[MMHN_K_COUNT];
+  double eval_ms;    /* host wall time spent inside evaluations */
   int64_t evals;
 } mmhn_counters;
 int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch,
                        int iters, int transpose, int jacobi, double* ms_per_launch);
+/* device-memory bandwidth of this GPU for a plain 16-byte-per-lane stream over arrays of `bytes` each
+ * (kind 0: copy, 1: triad a = b + s c), GB/s of the 2 x / 3 x bytes moved: the measured denominator next to the
+ * nominal HBM peak */
+int mmhn_bench_stream(mmhn_handle h, size_t bytes, int iters, int kind, double* gbps);
 int mmhn_get_counters(mmhn_handle h, mmhn_counters* out);
 int mmhn_reset_counters(mmhn_handle h);
 

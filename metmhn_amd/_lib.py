@@ -21,9 +21,15 @@ i8p = C.POINTER(C.c_int8)
 i64p = C.POINTER(C.c_int64)
 
 
+KERNEL_CLASSES = ("other_solve", "psolve_fwd", "psolve_adj", "pclass")      # MMHN_K_* of include/metmhn_amd.h
+
+
+class KernelCounter(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_int64), ("alg_bytes", C.c_double)]
+
+
 class Counters(C.Structure):
-    _fields_ = [("sweep_ms", C.c_double), ("sweep_launches", C.c_int64), ("sweep_alg_bytes", C.c_double),
-                ("eval_ms", C.c_double), ("evals", C.c_int64)]
+    _fields_ = [("kernel", KernelCounter * len(KERNEL_CLASSES)), ("eval_ms", C.c_double), ("evals", C.c_int64)]
 
 
 # name -> argtypes (every function returns int status unless noted)
@@ -42,9 +48,18 @@ SIGNATURES = {
     "mmhn_resolvent": [C.c_void_p, f64p, f64p, f64p, i8p, f64p, f64p, C.c_int],
     "mmhn_x_partial_Q_y": [C.c_void_p, f64p, i8p, f64p, f64p, f64p],
     "mmhn_x_partial_D_y": [C.c_void_p, f64p, f64p, i8p, f64p, f64p, f64p, f64p],
+    "mmhn_partial_diag_scal": [C.c_void_p, f64p, i8p, f64p, C.c_int, C.c_int, f64p],
     "mmhn_v_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
     "mmhn_v_resolvent": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, C.c_int],
     "mmhn_v_x_partial_Q_y": [C.c_void_p, f64p, i8p, f64p, f64p, f64p, f64p],
+    "mmhn_v_kron_diag": [C.c_void_p, f64p, i8p, f64p, f64p],
+    "mmhn_v_scal_d_pt": [C.c_void_p, f64p, f64p, i8p, f64p, f64p, f64p],
+    "mmhn_v_d_scal_d_pt": [C.c_void_p, f64p, f64p, i8p, f64p, C.c_int, f64p, f64p],
+    "mmhn_v_x_partial_D_y": [C.c_void_p, f64p, f64p, i8p, f64p, f64p, f64p, f64p],
+    "mmhn_comm_unique_id": [C.c_void_p],
+    "mmhn_comm_init": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "mmhn_comm_destroy": [C.c_void_p],
+    "mmhn_bench_stream": [C.c_void_p, C.c_size_t, C.c_int, C.c_int, f64p],
     "mmhn_bench_kronvec": [C.c_void_p, f64p, i8p, C.c_int64, C.c_int, C.c_int, C.c_int, f64p],
     "mmhn_simulate": [C.c_void_p, f64p, f64p, f64p, C.c_int64, C.c_uint64, i8p, i8p],
     "mmhn_get_counters": [C.c_void_p, C.POINTER(Counters)],

@@ -15,6 +15,8 @@
 //                                      k_class_marg, k_eq_flows, k_grad_rows, k_bit_marg
 //   7  per-patient assembly and deterministic cohort reduction  k_finalize, k_reduce
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>                 // types only: the library is opened at run time by mmhn_comm_init
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -96,9 +98,9 @@ struct Batch {
   DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   std::vector<int> ptoff;
-  std::vector<uint16_t> ptiles;
+  std::vector<uint32_t> ptiles;
   DevArr<int> d_ptoff;
-  DevArr<uint16_t> d_ptiles;
+  DevArr<uint32_t> d_ptiles;
   DevArr<PatRec> d_pats;
   DevArr<Desc> d_dJ, d_dS;
   DevArr<int2> d_mapJ, d_mapS, d_lmapJ, d_lmapS;
@@ -151,12 +153,101 @@ static void add_tiles(std::vector<int2>& map, int prob, int k) {
 struct EngineBase {
   virtual ~EngineBase() = default;
   int dtype = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
 };
+
+// Every ABI entry runs with the engine's GPU current and puts the caller's device back on exit, so engines on
+// different GPUs can live in one process (and a handle may be used from a thread whose current device differs).
+struct DevGuard {
+  int prev = -1;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) HIPCHECK(hipSetDevice(dev));
+    else prev = -1;
+  }
+  ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DevGuard(const DevGuard&) = delete;
+  DevGuard& operator=(const DevGuard&) = delete;
+};
+
+// RCCL entry points, resolved on first use (a single-GPU process never loads the library).  "librccl.so.1" is the
+// soname both ROCm and the PyTorch wheel ship: inside a torch.distributed process this is the copy already loaded.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl& rccl() {
+  static Rccl r;
+  if (r.lib) return r;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!lib) throw Fail{std::string("cannot load RCCL: ") + dlerror()};
+  auto sym = [&](const char* nm) {
+    void* f = dlsym(lib, nm);
+    if (!f) throw Fail{std::string("RCCL symbol missing: ") + nm};
+    return f;
+  };
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  r.lib = lib;
+  return r;
+}
+#define RCCLCHECK(expr)                                                                          \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess) throw Fail{std::string(#expr) + ": " + rccl().GetErrorString(r_)};    \
+  } while (0)
+
+// plain stream for mmhn_bench_stream: the denominator the HBM-bound kernels are compared with
+__global__ __launch_bounds__(256) void k_stream(double2* __restrict__ a, const double2* __restrict__ b,
+                                                const double2* __restrict__ c, size_t n16, int kind) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (kind == 0) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) a[i] = b[i];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+      const double2 u = b[i], v = c[i];
+      a[i] = make_double2(u.x + 3.0 * v.x, u.y + 3.0 * v.y);
+    }
+  }
+}
+
+// sums[2][stride] (EM, NM rows of k_reduce) -> the buffer layout of mmhn_cohort_sums (include/metmhn_amd.h)
+__global__ void k_pack_sums(const double* __restrict__ sums, int N, double n_em, double n_pat, double* __restrict__ o) {
+  const int st = 1 + N * N + 2 * N, NN = N * N;
+  const double* em = sums;
+  const double* nm = sums + st;
+  const int total = 4 + 2 * NN + 3 * N;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    double v;
+    if (e == 0) v = em[0];
+    else if (e == 1) v = nm[0];
+    else if (e == 2) v = n_em;
+    else if (e == 3) v = n_pat;
+    else {
+      int q = e - 4;
+      if (q < NN) v = em[1 + q];
+      else if ((q -= NN) < NN) v = nm[1 + q];
+      else if ((q -= NN) < N) v = em[1 + NN + q];
+      else if ((q -= N) < N) v = nm[1 + NN + q];
+      else v = em[1 + NN + N + (q - N)];
+    }
+    o[e] = v;
+  }
+}
 
 template <typename T>
 struct Engine : EngineBase {
-  int device = 0, n = 0, N = 0;
-  hipStream_t stream = nullptr;
+  int n = 0, N = 0;
   size_t ws_limit = 0;
   DevArr<Params<T>> d_par;
   std::vector<Params<T>> h_par;
@@ -169,8 +260,11 @@ struct Engine : EngineBase {
   // workspace (sized for the largest batch)
   DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS, tabJ, tabS;
   int pi_owner = -1, qJ_owner = -1;   // batch whose (pruned) layout the zero-initialised buffers hold
-  DevArr<double> lp, out, sums;
+  DevArr<double> lp, out, sums, abi_sums;
   DevArr<JLink<T>> links;
+  // patient shards on several GPUs: one communicator per engine, the all-reduce runs on the engine's stream
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
   // popcount-ordered state permutations of every tile size (k_tsolve step B)
   DevArr<uint16_t> d_perm;
   DevArr<int> d_lvl;
@@ -182,10 +276,12 @@ struct Engine : EngineBase {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   std::vector<double> ev_bytes;
+  std::vector<int> ev_slot;           // MMHN_K_* class of the timed launch
 
-  Engine(int dev, int n_mut) : device(dev), n(n_mut), N(n_mut + 1) {
+  Engine(int dev, int n_mut) : n(n_mut), N(n_mut + 1) {
+    device = dev;
     REQUIRE(n_mut >= 1 && n_mut < MAXN, "n_mut must be in [1, 31]");
-    HIPCHECK(hipSetDevice(device));
+    DevGuard guard(device);
     HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     d_par.alloc(NPSET);
     h_par.resize(NPSET);
@@ -236,10 +332,11 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_class_marg<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  ~Engine() override {
-    (void)hipSetDevice(device);
+  ~Engine() override {                       // runs under the DevGuard of mmhn_destroy
+    comm_destroy();
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
   }
   int stride() const { return 1 + N * N + 2 * N; }
 
@@ -292,6 +389,7 @@ struct Engine : EngineBase {
       e1 = ev_pool[ev_used].second;
       ++ev_used;
       ev_bytes.push_back(alg_bytes);
+      ev_slot.push_back(MMHN_K_OTHER_SOLVE);
       HIPCHECK(hipEventRecord(e0, stream));
     }
     const size_t lds = sweep_lds(maxk);
@@ -308,19 +406,22 @@ struct Engine : EngineBase {
     for (size_t i = 0; i < ev_used; ++i) {
       float ms = 0;
       HIPCHECK(hipEventElapsedTime(&ms, ev_pool[i].first, ev_pool[i].second));
-      cnt.sweep_ms += ms;
-      cnt.sweep_launches += 1;
-      cnt.sweep_alg_bytes += ev_bytes[i];
+      mmhn_kernel_counter& c = cnt.kernel[ev_slot[i]];
+      c.ms += ms;
+      c.launches += 1;
+      c.alg_bytes += ev_bytes[i];
     }
     ev_used = 0;
     ev_bytes.clear();
+    ev_slot.clear();
   }
 
-  void launch_diag(const Desc* descs, const int2* map, int ntiles, const T* p, T* outp, const T* dvec, int what) {
+  void launch_diag(const Desc* descs, const int2* map, int ntiles, const T* p, T* outp, const T* dvec, int what,
+                   int pbit = -1) {
     if (ntiles == 0) return;
     const size_t lds = DESC_PAD + ((size_t)4 * N * 64 + 256) * sizeof(T);
     hipLaunchKernelGGL((k_diag<T>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, outp, dvec,
-                       what, N);
+                       what, N, pbit);
     HIPCHECK(hipGetLastError());
   }
   // dj != nullptr (joint kinds): one extra row per problem with the observation-rate gradient
@@ -351,7 +452,7 @@ struct Engine : EngineBase {
   }
   // timed launch helper shared by the two solvers
   template <typename F>
-  void timed(double alg_bytes, F&& launch) {
+  void timed(int slot, double alg_bytes, F&& launch) {
     if (ev_used == ev_pool.size()) {
       hipEvent_t a, b;
       HIPCHECK(hipEventCreate(&a));
@@ -361,6 +462,7 @@ struct Engine : EngineBase {
     hipEvent_t e0 = ev_pool[ev_used].first, e1 = ev_pool[ev_used].second;
     ++ev_used;
     ev_bytes.push_back(alg_bytes);
+    ev_slot.push_back(slot);
     HIPCHECK(hipEventRecord(e0, stream));
     launch();
     HIPCHECK(hipGetLastError());
@@ -389,7 +491,7 @@ struct Engine : EngineBase {
     const int dl_cap = psolve_dl_cap(mk);
     const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
-    timed(bytes, [&]() {
+    timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
 #define PS_ARGS dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap
       if (b.all_multi) {
         if (tr) hipLaunchKernelGGL((k_psolve<T, true, true>), PS_ARGS);
@@ -423,7 +525,7 @@ struct Engine : EngineBase {
       if (cntl == 0) continue;
       // compulsory traffic of a tile: write y (+ read dense rhs, + read the lidg vector when there is one)
       const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);   // modes 1-3: rhs is not a 2^k vector
-      timed(per_tile * cntl, [&]() {
+      timed(MMHN_K_OTHER_SOLVE, per_tile * cntl, [&]() {
         const dim3 g(cntl), bk(TSB);
 #define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab, links.p, qS.p
         if (lidg) {
@@ -524,13 +626,18 @@ struct Engine : EngineBase {
         }
       }
       REQUIRE(!hasJ || dj.k <= MAXK, "too many active events for one patient");
-      // would the batch overflow the workspace?
-      Batch probe;
-      probe.vecJ = cur.vecJ + (hasJ ? (1ll << dj.k) : 0);
-      probe.vecS = cur.vecS + (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
-      probe.asize = cur.asize + (hasJ ? a_size(dj) : 0);
-      const size_t need = (size_t)((use_jacobi ? 4 : 2) * probe.vecJ + 4 * probe.vecS + probe.asize + cur.tabJ + cur.tabS) * sizeof(T);
-      const size_t have = (size_t)((use_jacobi ? 4 : 2) * cur.vecJ + 4 * cur.vecS + cur.asize + cur.tabJ + cur.tabS) * sizeof(T);
+      // would the batch overflow the workspace?  State vectors, class-marginal arrays, the per-evaluation tables
+      // (incl. the incoming problems') and the per-problem / per-patient result buffers
+      const long long nvJ = hasJ ? (1ll << dj.k) : 0, nvS = (has0 ? (1ll << ds0.k) : 0) + (has1 ? (1ll << ds1.k) : 0);
+      const long long ntab = (hasJ ? table_size(dj) : 0) + (has0 ? table_size(ds0) : 0) + (has1 ? table_size(ds1) : 0);
+      auto footprint = [&](long long vJ, long long vS, long long as, long long tabs, size_t nJp, size_t nSp, size_t npat) {
+        const size_t small = (nSp * (size_t)(N * N + 64 + 1) + nJp * (size_t)(3 * N * N + 3 * N + 64)) * sizeof(T) +
+                             nJp * sizeof(JLink<T>) + npat * ((size_t)stride() + 1) * sizeof(double) + npat * 2 * sizeof(T);
+        return (size_t)((use_jacobi ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
+      };
+      const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
+                                    cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
+      const size_t have = footprint(cur.vecJ, cur.vecS, cur.asize, cur.tabJ + cur.tabS, cur.dJ.size(), cur.dS.size(), cur.pats.size());
       if (!cur.pats.empty() && (need > ws_limit || (soft_target > 0 && (double)have >= soft_target))) flush();
       if (hasJ) {
         dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
@@ -594,7 +701,7 @@ struct Engine : EngineBase {
             const uint32_t Ht = (uint32_t)b.mapJ[pos].y;
             const bool multi = dj.seedbit >= TB && popc(dj.pairP) <= TB;
             const bool seeded_tile = multi && ((Ht << TB) >> dj.seedbit) & 1u;
-            if (multi ? seeded_tile : !dead_tile(dj, Ht)) b.ptiles.push_back((uint16_t)Ht);
+            if (multi ? seeded_tile : !dead_tile(dj, Ht)) b.ptiles.push_back(Ht);
             ++pos;
           }
           b.ptoff.push_back((int)b.ptiles.size());
@@ -637,7 +744,6 @@ struct Engine : EngineBase {
   void evaluate(const double* lt, const double* ldp, const double* ldm, bool grad, double* host_sums,
                 double* host_out) {
     auto t0 = std::chrono::steady_clock::now();
-    HIPCHECK(hipSetDevice(device));
     build_params(lt, ldp, ldm);
     const int st = stride();
     HIPCHECK(hipMemsetAsync(sums.p, 0, 2 * st * sizeof(double), stream));
@@ -709,8 +815,12 @@ struct Engine : EngineBase {
           // 6 joint gradient
           zero(Abuf.p, b.asize);
           if (per_patient) {
-            hipLaunchKernelGGL((k_pclass<T>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
-                               pi.p, qJ.p, Abuf.p);
+            // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
+            const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
+            timed(MMHN_K_PCLASS, mbytes, [&]() {
+              hipLaunchKernelGGL((k_pclass<T>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
+                                 pi.p, qJ.p, Abuf.p);
+            });
             if (!b.mapX.empty())
               hipLaunchKernelGGL((k_class_marg<T>), dim3((unsigned)b.mapX.size()), dim3(CMB), 2 * sizeof(T) << TB, stream,
                                  b.d_dJ.p, b.d_mapX.p, pi.p, qJ.p, Abuf.p);
@@ -744,29 +854,45 @@ struct Engine : EngineBase {
           std::memcpy(host_out + (size_t)b.pats[i].row * st, tmp.data() + (size_t)i * st, st * sizeof(double));
       }
     }
-    std::vector<double> hs(2 * st);
-    HIPCHECK(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipStreamSynchronize(stream));
+    if (host_sums) {
+      std::vector<double> hs(2 * st);
+      HIPCHECK(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIPCHECK(hipStreamSynchronize(stream));
+      std::memcpy(host_sums, hs.data(), hs.size() * sizeof(double));
+      finish_eval(t0);
+    }
+  }
+  void finish_eval(std::chrono::steady_clock::time_point t0) {
     collect_events();
-    if (host_sums) std::memcpy(host_sums, hs.data(), hs.size() * sizeof(double));
     cnt.eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     cnt.evals += 1;
   }
 
-  // sums layout of the C ABI (include/metmhn_amd.h)
+  // sums layout of the C ABI (include/metmhn_amd.h): packed on the device, summed over the ranks of the
+  // communicator (one RCCL all-reduce on this stream, regularized_optimization.py:256-266 needs nothing else),
+  // then one download and one synchronisation per evaluation
   void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
-    const int st = stride();
-    std::vector<double> hs(2 * st);
-    evaluate(lt, ldp, ldm, grad, hs.data(), nullptr);
-    const double* em = hs.data();
-    const double* nm = hs.data() + st;
-    o[0] = em[0]; o[1] = nm[0]; o[2] = n_em; o[3] = (double)n_pat;
-    double* q = o + 4;
-    std::memcpy(q, em + 1, N * N * sizeof(double)); q += N * N;
-    std::memcpy(q, nm + 1, N * N * sizeof(double)); q += N * N;
-    std::memcpy(q, em + 1 + N * N, N * sizeof(double)); q += N;
-    std::memcpy(q, nm + 1 + N * N, N * sizeof(double)); q += N;
-    std::memcpy(q, em + 1 + N * N + N, N * sizeof(double));
+    auto t0 = std::chrono::steady_clock::now();
+    const int total = 4 + 2 * N * N + 3 * N;
+    abi_sums.alloc(total);
+    evaluate(lt, ldp, ldm, grad, nullptr, nullptr);
+    hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, abi_sums.p);
+    HIPCHECK(hipGetLastError());
+    if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
+    HIPCHECK(hipMemcpyAsync(o, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    finish_eval(t0);
+  }
+
+  void comm_init(const ncclUniqueId& id, int rank, int nranks) {
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: rank / n_ranks out of range");
+    comm_destroy();
+    RCCLCHECK(rccl().CommInitRank(&comm, nranks, id, rank));
+    comm_rank = rank; comm_size = nranks;
+  }
+  void comm_destroy() {
+    if (comm) { (void)rccl().CommDestroy(comm); comm = nullptr; }
+    comm_rank = 0; comm_size = 1;
   }
 
   // ---------------------------------------------------------------- single-problem primitives (API / tests)
@@ -819,13 +945,60 @@ struct Engine : EngineBase {
     if (diag) launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, KD_ADDQP);
     down(y, m.b.p, V);
   }
-  void api_diag(const Desc& d, const double* p, double* outp, int what) {
+  void api_diag(const Desc& d, const double* p, double* outp, int what, int pbit = -1) {
     Mini m; mini_setup(m, d);
     const size_t V = (size_t)1 << d.k;
     if (p) up(m.a, p, V);
     m.b.alloc(V);
-    launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, what);
+    launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, what, pbit);
     down(outp, m.b.p, V);
+  }
+  // vanilla.x_partial_D_y (vanilla.py:190-203): weighted bit marginals of x * y under the two parts of scal_d_pt
+  void api_xDy_single(const Desc& d0, const double* x, const double* y, double* ddp, double* ddm) {
+    Mini m; mini_setup(m, d0);
+    const size_t V = (size_t)1 << d0.k;
+    up(m.a, y, V);
+    up(m.b, x, V);
+    m.e.alloc(64);
+    zero(m.e.p, 64);
+    hipLaunchKernelGGL((k_bit_marg<T>), dim3(m.ntiles), dim3(BLOCK), 0, stream, m.dd.p, m.map.p, d_par.p, m.a.p,
+                       m.b.p, m.e.p);
+    HIPCHECK(hipGetLastError());
+    double bm[64];
+    down(bm, m.e.p, 64);
+    for (int i = 0; i < N; ++i) {
+      const int b = d0.bitP[i];
+      ddp[i] = b >= 0 ? bm[b] : 0.0;
+      ddm[i] = b >= 0 ? bm[32 + b] : 0.0;
+    }
+  }
+  // achieved device-memory bandwidth of this GPU for a plain stream: kind 0 copy (b = a), 1 triad (a = b + s c);
+  // 16 bytes per lane, `bytes` per array (>> Infinity Cache), HIP events around `iters` launches; GB/s of the
+  // bytes the kernel is asked to move (copy 2 x, triad 3 x bytes)
+  double bench_stream(size_t bytes, int iters, int kind) {
+    REQUIRE(bytes >= (1u << 20) && iters >= 1 && (kind == 0 || kind == 1), "bench_stream: bad arguments");
+    const size_t n16 = bytes / 16;
+    DevArr<double2> a, b, c;
+    a.alloc(n16); b.alloc(n16);
+    if (kind == 1) c.alloc(n16);
+    HIPCHECK(hipMemsetAsync(a.p, 0, n16 * 16, stream));
+    HIPCHECK(hipMemsetAsync(b.p, 0, n16 * 16, stream));
+    if (kind == 1) HIPCHECK(hipMemsetAsync(c.p, 0, n16 * 16, stream));
+    auto run = [&]() {
+      hipLaunchKernelGGL(k_stream, dim3(256 * 8), dim3(256), 0, stream, a.p, b.p, c.p, n16, kind);
+    };
+    run();
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) run();
+    HIPCHECK(hipEventRecord(e1, stream));
+    HIPCHECK(hipEventSynchronize(e1));
+    HIPCHECK(hipGetLastError());
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return (double)(kind == 0 ? 2 : 3) * (double)(n16 * 16) * iters / ((double)ms * 1e6);
   }
   void api_resolvent(Desc d, const double* dvec, const double* x, double* y, bool tr) {
     if (dvec) d.obs = OBS_VEC;
@@ -979,6 +1152,11 @@ struct mmhn_engine {
   catch (const Fail& f) { g_err = f.msg; return 1; } \
   catch (const std::exception& e) { g_err = e.what(); return 2; }
 
+// engine's device current for the rest of the entry point
+#define GUARD(h)                            \
+  REQUIRE(h && h->impl, "null handle");     \
+  DevGuard dev_guard_(h->impl->device)
+
 #define DISPATCH(h, call)                                             \
   do {                                                                \
     REQUIRE(h && h->impl, "null handle");                             \
@@ -1010,12 +1188,19 @@ int mmhn_create(int device_id, int n_mut, int dtype, mmhn_handle* out) {
 
 void mmhn_destroy(mmhn_handle h) {
   if (!h) return;
-  delete h->impl;
+  try {
+    if (h->impl) {
+      DevGuard guard(h->impl->device);     // device memory, stream and communicator are released on their GPU
+      delete h->impl;
+    }
+  } catch (...) {
+  }
   delete h;
 }
 
 int mmhn_set_workspace_limit(mmhn_handle h, size_t bytes) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(bytes >= (size_t)1 << 20, "workspace limit below 1 MiB");
   DISPATCH(h, ws_limit = bytes);
   API_END
@@ -1023,6 +1208,7 @@ int mmhn_set_workspace_limit(mmhn_handle h, size_t bytes) {
 
 int mmhn_set_cohort(mmhn_handle h, const int8_t* dat, int64_t n_pat, int n_cols) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(dat || n_pat == 0, "null dat");
   DISPATCH(h, set_cohort(dat, n_pat, n_cols));
   API_END
@@ -1037,6 +1223,7 @@ static void weights(double n_em, double n_pat, double perc_met, double* w, doubl
 int mmhn_cohort_sums(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, int with_grad,
                      double* sums) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && ldp && ldm && sums, "null pointer");
   DISPATCH(h, cohort_sums(lt, ldp, ldm, with_grad != 0, sums));
   API_END
@@ -1045,6 +1232,7 @@ int mmhn_cohort_sums(mmhn_handle h, const double* lt, const double* ldp, const d
 int mmhn_score_and_grad(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, double perc_met,
                         double* score, double* d_theta, double* d_dp, double* d_dm) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && ldp && ldm && score, "null pointer");
   const int N = h->n + 1;
   const bool grad = d_theta && d_dp && d_dm;
@@ -1073,6 +1261,7 @@ int mmhn_score(mmhn_handle h, const double* lt, const double* ldp, const double*
 int mmhn_patient_grads(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, double* lp,
                        double* d_theta, double* d_dp, double* d_dm) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && ldp && ldm && lp, "null pointer");
   const int N = h->n + 1, st = 1 + N * N + 2 * N;
   long long np = 0;
@@ -1099,6 +1288,7 @@ int mmhn_patient_grads(mmhn_handle h, const double* lt, const double* ldp, const
 int mmhn_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const double* p, double* y, int diag,
                  int transpose) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && p && y, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1107,6 +1297,7 @@ int mmhn_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const dou
 }
 int mmhn_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, double* out) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && out, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1115,6 +1306,7 @@ int mmhn_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, double*
 }
 int mmhn_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, const double* p, double* y, int which) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(log_d && state && p && y, "null pointer");
   REQUIRE(which == 0 || which == 1, "which must be 0 (d_p) or 1 (d_m)");
   const Desc d = JOINT_DESC(state);
@@ -1127,6 +1319,7 @@ int mmhn_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, cons
 }
 int mmhn_obs_states(mmhn_handle h, const int8_t* state, int pt_first, int64_t* idx, int64_t* count) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(h && state && idx && count, "null pointer");
   obs_indices(JOINT_DESC(state), pt_first != 0, idx, count);
   API_END
@@ -1134,6 +1327,7 @@ int mmhn_obs_states(mmhn_handle h, const int8_t* state, int pt_first, int64_t* i
 int mmhn_resolvent(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, const int8_t* state,
                    const double* x, double* y, int transpose) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && ldp && ldm && state && x && y, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, ldp, ldm));
@@ -1143,6 +1337,7 @@ int mmhn_resolvent(mmhn_handle h, const double* lt, const double* ldp, const dou
 int mmhn_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, const double* x, const double* y,
                        double* G) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && x && y && G, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1152,6 +1347,7 @@ int mmhn_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, con
 int mmhn_x_partial_D_y(mmhn_handle h, const double* ldp, const double* ldm, const int8_t* state, const double* x,
                        const double* y, double* d_dp, double* d_dm) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(ldp && ldm && state && x && y && d_dp && d_dm, "null pointer");
   const Desc d = JOINT_DESC(state);
   const int N = h->n + 1;
@@ -1161,10 +1357,33 @@ int mmhn_x_partial_D_y(mmhn_handle h, const double* ldp, const double* ldm, cons
   API_END
 }
 
+int mmhn_partial_diag_scal(mmhn_handle h, const double* log_d, const int8_t* state, const double* p, int i, int which,
+                           double* y) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(log_d && state && p && y, "null pointer");
+  REQUIRE(which == 0 || which == 1, "which must be 0 (d_p) or 1 (d_m)");
+  const int n = h->n, N = n + 1;
+  REQUIRE(i >= 0 && i <= n, "event index out of range");
+  const Desc d = JOINT_DESC(state);
+  REQUIRE(d.seedbit >= 0, "partial_diag_scal needs an active seeding slot");
+  // kronvec.py:632-644, :704-710: zero when the tumour's slot of event i is inactive; i == n: the seeding bit
+  const int bit = i == n ? d.seedbit : (which == 0 ? d.bitP[i] : d.bitM[i]);
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), which == 0 ? log_d : nullptr, which == 1 ? log_d : nullptr));
+  if (bit < 0) {
+    std::memset(y, 0, sizeof(double) << d.k);
+  } else {
+    DISPATCH(h, api_diag(d, p, y, which == 0 ? KD_DP : KD_DM, bit));
+  }
+  API_END
+}
+
 // ---- single-tumour primitives
 int mmhn_v_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const double* p, double* y, int diag,
                    int transpose) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && p && y, "null pointer");
   const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1174,6 +1393,7 @@ int mmhn_v_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const d
 int mmhn_v_resolvent(mmhn_handle h, const double* lt, const int8_t* state, const double* d_rates, const double* x,
                      double* y, int transpose) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && x && y, "null pointer");
   const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1183,6 +1403,7 @@ int mmhn_v_resolvent(mmhn_handle h, const double* lt, const int8_t* state, const
 int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, const double* x, const double* y,
                          double* G, double* d_diag) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && x && y && G, "null pointer");
   const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1190,14 +1411,96 @@ int mmhn_v_x_partial_Q_y(mmhn_handle h, const double* lt, const int8_t* state, c
   API_END
 }
 
+int mmhn_v_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, const double* diag, double* out) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(lt && state && out, "null pointer");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_ONE);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_diag(d, diag, out, diag ? KD_QP : KD_DQ));
+  API_END
+}
+int mmhn_v_scal_d_pt(mmhn_handle h, const double* ldp, const double* ldm, const int8_t* state, const double* vec,
+                     double* out_p, double* out_m) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(ldp && ldm && state && vec && out_p && out_m, "null pointer");
+  REQUIRE(state[h->n] == 1, "scal_d_pt needs the seeding event in the state (vanilla.py:142)");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_MET);
+  const int N = h->n + 1;
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), ldp, ldm));
+  DISPATCH(h, api_diag(d, vec, out_p, KD_SDP));
+  DISPATCH(h, api_diag(d, vec, out_m, KD_DM));
+  API_END
+}
+int mmhn_v_d_scal_d_pt(mmhn_handle h, const double* ldp, const double* ldm, const int8_t* state, const double* vec,
+                       int i, double* out_p, double* out_m) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(ldp && ldm && state && vec && out_p && out_m, "null pointer");
+  const int n = h->n, N = n + 1;
+  REQUIRE(i >= 0 && i <= n, "event index out of range");
+  REQUIRE(state[n] == 1, "d_scal_d_pt needs the seeding event in the state");
+  const Desc d = make_single(state, n, PS_THETA, OBS_MET);
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), ldp, ldm));
+  // vanilla.py:182-187: inactive event -> zeros; i == n -> (0, d_m part); otherwise both parts restricted to "i happened"
+  if (d.bitP[i] < 0 || i == n) std::memset(out_p, 0, sizeof(double) << d.k);
+  else DISPATCH(h, api_diag(d, vec, out_p, KD_SDP, d.bitP[i]));
+  if (d.bitP[i] < 0) std::memset(out_m, 0, sizeof(double) << d.k);
+  else DISPATCH(h, api_diag(d, vec, out_m, KD_DM, i == n ? -1 : d.bitP[i]));
+  API_END
+}
+int mmhn_v_x_partial_D_y(mmhn_handle h, const double* ldp, const double* ldm, const int8_t* state, const double* x,
+                         const double* y, double* d_dp, double* d_dm) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(ldp && ldm && state && x && y && d_dp && d_dm, "null pointer");
+  REQUIRE(state[h->n] == 1, "x_partial_D_y needs the seeding event in the state");
+  const Desc d = make_single(state, h->n, PS_THETA, OBS_MET);
+  const int N = h->n + 1;
+  std::vector<double> lt((size_t)N * N, 0.0);
+  DISPATCH(h, build_params(lt.data(), ldp, ldm));
+  DISPATCH(h, api_xDy_single(d, x, y, d_dp, d_dm));
+  API_END
+}
+
+// ---- patient shards on several GPUs: one RCCL communicator per engine
+int mmhn_comm_unique_id(void* id128) {
+  API_BEGIN
+  REQUIRE(id128, "null pointer");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  RCCLCHECK(rccl().GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  API_END
+}
+int mmhn_comm_init(mmhn_handle h, const void* id128, int rank, int n_ranks) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(id128, "null pointer");
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  DISPATCH(h, comm_init(id, rank, n_ranks));
+  API_END
+}
+int mmhn_comm_destroy(mmhn_handle h) {
+  API_BEGIN
+  GUARD(h);
+  DISPATCH(h, comm_destroy());
+  API_END
+}
+
 // ---- Gillespie sampler
 int mmhn_simulate(mmhn_handle h, const double* lt, const double* pt_d_ef, const double* mt_d_ef, int64_t n_sim,
                   uint64_t seed, int8_t* dat_out, int8_t* orders_out) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(h && lt && pt_d_ef && mt_d_ef && dat_out, "null pointer");
   REQUIRE(n_sim >= 0, "n_sim must be non-negative");
   const int N = h->n + 1;
-  REQUIRE(N <= SIM_MAXN, "too many events for the sampler");
+  REQUIRE(N < SIM_MAXN, "too many events for the sampler (n_mut <= 30: event and diagnosis flags share one 32-bit set)");
   if (n_sim > 0) {
     const size_t W = (size_t)2 * h->n + 2, L = (size_t)2 * N + 2;
     DevArr<double> d_lt, d_dp, d_dm;
@@ -1208,10 +1511,11 @@ int mmhn_simulate(mmhn_handle h, const double* lt, const double* pt_d_ef, const 
     HIPCHECK(hipMemcpy(d_dp.p, pt_d_ef, sizeof(double) * N, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(d_dm.p, mt_d_ef, sizeof(double) * N, hipMemcpyHostToDevice));
     const unsigned grid = (unsigned)((n_sim + SIM_BLOCK - 1) / SIM_BLOCK);
-    hipLaunchKernelGGL(k_gillespie, dim3(grid), dim3(SIM_BLOCK), 0, 0, d_lt.p, d_dp.p, d_dm.p, N, (long long)n_sim, seed,
+    hipStream_t st = h->impl->stream;
+    hipLaunchKernelGGL(k_gillespie, dim3(grid), dim3(SIM_BLOCK), 0, st, d_lt.p, d_dp.p, d_dm.p, N, (long long)n_sim, seed,
                        d_dat.p, orders_out ? d_ord.p : nullptr);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipStreamSynchronize(st));
     HIPCHECK(hipMemcpy(dat_out, d_dat.p, (size_t)n_sim * W, hipMemcpyDeviceToHost));
     if (orders_out) HIPCHECK(hipMemcpy(orders_out, d_ord.p, (size_t)n_sim * L, hipMemcpyDeviceToHost));
   }
@@ -1222,6 +1526,7 @@ int mmhn_simulate(mmhn_handle h, const double* lt, const double* pt_d_ef, const 
 int mmhn_bench_kronvec(mmhn_handle h, const double* lt, const int8_t* state, int64_t batch, int iters,
                        int transpose, int jacobi, double* ms_per_launch) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(lt && state && ms_per_launch, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
@@ -1231,8 +1536,30 @@ int mmhn_bench_kronvec(mmhn_handle h, const double* lt, const int8_t* state, int
     *ms_per_launch = static_cast<Engine<float>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0);
   API_END
 }
+int mmhn_bench_stream(mmhn_handle h, size_t bytes, int iters, int kind, double* gbps) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(gbps, "null pointer");
+  if (h->dtype == MMHN_F64) *gbps = static_cast<Engine<double>*>(h->impl)->bench_stream(bytes, iters, kind);
+  else *gbps = static_cast<Engine<float>*>(h->impl)->bench_stream(bytes, iters, kind);
+  API_END
+}
+#ifdef MMHN_STAMPS
+// diagnostic builds only: shader cycles wave 0 of every k_psolve workgroup spent per phase ([0..7] forward, [8..15] adjoint)
+int mmhn_debug_stamps(mmhn_handle h, double* out16, int reset) {
+  API_BEGIN
+  GUARD(h);
+  unsigned long long v[16];
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_stamps), sizeof(v)));
+  for (int i = 0; i < 16; ++i) out16[i] = (double)v[i];
+  if (reset) { std::memset(v, 0, sizeof(v)); HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), v, sizeof(v))); }
+  API_END
+}
+#endif
 int mmhn_get_counters(mmhn_handle h, mmhn_counters* out) {
   API_BEGIN
+  GUARD(h);
   REQUIRE(h && h->impl && out, "null pointer");
   if (h->dtype == MMHN_F64) *out = static_cast<Engine<double>*>(h->impl)->cnt;
   else *out = static_cast<Engine<float>*>(h->impl)->cnt;
@@ -1240,6 +1567,7 @@ int mmhn_get_counters(mmhn_handle h, mmhn_counters* out) {
 }
 int mmhn_reset_counters(mmhn_handle h) {
   API_BEGIN
+  GUARD(h);
   DISPATCH(h, cnt = mmhn_counters{});
   API_END
 }

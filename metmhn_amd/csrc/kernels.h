@@ -742,6 +742,21 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 // single launch, and the neighbour tiles a tile reads were written moments earlier by the same CU.
 // Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
 // ------------------------------------------------------------------------------------
+#ifdef MMHN_STAMPS
+// diagnostic build only (scripts/build_variants.sh): wave 0 of every workgroup sums the shader cycles it spends in
+// each phase of a tile; the sums leave through a buffer nothing else reads (mmhn_debug_stamps)
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_prev = 0, st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const bool st_on = threadIdx.x < 64
+#define STAMP_START do { if (st_on) { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define STAMP(i) do { if (st_on) { __builtin_amdgcn_sched_barrier(0); const unsigned long long st_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f); st_sum[i] += st_now - st_prev; st_prev = st_now; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define STAMP_FLUSH(base) do { if (threadIdx.x == 0) for (int si = 0; si < 8; ++si) atomicAdd(&g_stamps[(base) + si], st_sum[si]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH(base)
+#endif
+
 constexpr int PS_DL = 528;                      // most LDS entries k_psolve spends on the per-tile dP / dM slices (2^9 + 2^3 ... 2^6 + 2^6)
 
 // MULTI: every problem of the launch is a multi-tile space whose seed = 0 part takes the lattice solve, so every
@@ -749,7 +764,7 @@ constexpr int PS_DL = 528;                      // most LDS entries k_psolve spe
 template <typename T, bool TR, bool MULTI>
 __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
                                                    const int* __restrict__ pt_off,
-                                                   const uint16_t* __restrict__ ptiles,
+                                                   const uint32_t* __restrict__ ptiles,
                                                    const Params<T>* __restrict__ par, T* y, int rhs_mode,
                                                    const uint16_t* __restrict__ perm, int maxk,
                                                    const T* __restrict__ tab,
@@ -851,9 +866,13 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       __syncthreads();
     }
   };
+  STAMP_DECL;
+  STAMP_START;
   if (eq_block && !TR) solve_eq_block();
+  STAMP(7);
   uint32_t Hprev = 0xffffffffu;                                 // tile whose solution yt still holds
   for (int it = 0; it < ntile; ++it) {
+    STAMP_START;
     const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
     const uint32_t xhi = H << t;
     // keep nothing thread-dependent live across tiles (64 VGPRs for two workgroups per CU): everything below is
@@ -882,6 +901,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       pxt[384 + tid - 64] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
     }
     __syncthreads();
+    STAMP(0);
     for (int e = tid; e < k * 64; e += TSB) Utab[e] = Urow[e] * hx[e >> 6];
     if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) dl[dli] = dval;
     const bool seed_hi = (xhi >> seedb) & 1u;
@@ -911,6 +931,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       }
     }
     __syncthreads();                                   // Utab complete; the previous tile's stores have landed
+    STAMP(1);
     const bool fast = MULTI || (t == TB && seedb >= t && seed_hi);
     // ---- step A: transitions that cross the tile boundary
     // one move (bit b; kind 1 = the pair move of P bit b) with every condition evaluated per state
@@ -975,6 +996,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
       if (xl < nelem) yt[xl] = acc[j];
     }
+    STAMP(2);
     // popcount order of this thread's states and their inverse diagonals (after step A: registers are tight)
     uint32_t px[NJ];
     int plev[NJ];
@@ -998,6 +1020,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       lid[j] = v;
     }
     __syncthreads();
+    STAMP(3);
     // ---- step B: popcount-ordered substitution inside the tile
     for (int s = 0; s <= t; ++s) {
       const int level = TR ? t - s : s;
@@ -1050,6 +1073,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
       }
       __syncthreads();
     }
+    STAMP(4);
     // ---- step C: 16 bytes per lane when the tile is full
     if (t == TB) {
       struct alignas(16) vec16 { T v[16 / sizeof(T)]; };
@@ -1064,11 +1088,15 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
     // precedes the next tile's neighbour loads
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
+    STAMP(5);
   }
+  STAMP_START;
   if (eq_block && TR) {
     __syncthreads();                                             // the seeded tiles' q has landed
     solve_eq_block();
   }
+  STAMP(7);
+  STAMP_FLUSH(TR ? 8 : 0);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1076,16 +1104,21 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
 //   KD_DQ    out = diag(Q)                           (kron_diag, kronvec.py:964-999)
 //   KD_LIDG  out = 1 / (Dobs - diag(Q))              (likelihood.py:249-250, vanilla.py:294)
 //   KD_ADDQP out += diag(Q) * p                      (completes kronvec(diag=True))
-//   KD_DP    out = D_p * p,  KD_DM  out = D_m * p    (diag_scal_p / diag_scal_m)
+//   KD_DP    out = D_p * p,  KD_DM  out = D_m * p    (diag_scal_p / diag_scal_m; on a single-tumour space KD_DM
+//            is the d_m part of vanilla.scal_d_pt, vanilla.py:125-142)
+//   KD_QP    out = diag(Q) * p                       (vanilla.kron_diag with a caller-supplied vector, :247-260)
+//   KD_SDP   out = [seeding clear] prod d_p * p      (the d_p part of vanilla.scal_d_pt)
+// pbit >= 0 keeps only the states that contain index bit pbit (partial_diag_scal_p/m, kronvec.py:605-710:
+// the derivative of a Kronecker diagonal w.r.t. one log-rate is the diagonal restricted to "event happened").
 // ------------------------------------------------------------------------------------
-enum { KD_DQ = 0, KD_LIDG = 1, KD_ADDQP = 2, KD_DP = 3, KD_DM = 4 };
+enum { KD_DQ = 0, KD_LIDG = 1, KD_ADDQP = 2, KD_DP = 3, KD_DM = 4, KD_QP = 5, KD_SDP = 6 };
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
                                                 const int2* __restrict__ map,
                                                 const Params<T>* __restrict__ par,
                                                 const T* __restrict__ p, T* out,
-                                                const T* __restrict__ dvec, int what, int maxN) {
+                                                const T* __restrict__ dvec, int what, int maxN, int pbit) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* LcP = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -1156,7 +1189,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
     const bool ss = seed_set(d, x);
     const bool sbit = d.seedbit >= 0 && ((x >> d.seedbit) & 1u);
     T dq = 0;
-    if (what <= KD_ADDQP) {
+    if (what <= KD_ADDQP || what == KD_QP) {
       if (!joint) {
         for (int i = 0; i < N; ++i)
           if (d.bitP[i] < 0 || !((x >> d.bitP[i]) & 1u)) dq -= LcP[i * 64 + lane] * UcP[i * 64 + r];
@@ -1186,9 +1219,14 @@ __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
       res = out[base + x] + dq * p[base + x];
     } else if (what == KD_DP) {
       res = (sbit ? A * P.dp[n] : A) * p[base + x];
-    } else {
+    } else if (what == KD_DM) {
       res = (sbit ? B * P.dm[n] : T(0)) * p[base + x];
+    } else if (what == KD_QP) {
+      res = dq * p[base + x];
+    } else {
+      res = sbit ? T(0) : A * p[base + x];
     }
+    if (pbit >= 0 && !((x >> pbit) & 1u)) res = 0;
     out[base + x] = res;
   }
 }

@@ -9,6 +9,27 @@ from . import _lib
 from ._lib import f64p, i8p, i64p
 
 F64, F32 = 0, 1
+_DEFAULT = {"device": None}
+
+
+def set_default_device(device: int | None):
+    """GPU used by every Engine created without an explicit `device` (jx mirrors, simulations, the objective).
+    None: LOCAL_RANK of a torch.distributed launch, else 0."""
+    _DEFAULT["device"] = None if device is None else int(device)
+
+
+def default_device() -> int:
+    if _DEFAULT["device"] is not None:
+        return _DEFAULT["device"]
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def unique_id() -> bytes:
+    """128-byte RCCL id for Engine.comm_init (call on one rank, hand to the others by any host channel)."""
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().mmhn_comm_unique_id(buf))
+    return buf.raw
 
 
 def _f(a):
@@ -24,8 +45,11 @@ def _s(a):
 class Engine:
     """Owns a mmhn_handle.  `n_mut` mutations -> N = n_mut + 1 events incl. seeding."""
 
-    def __init__(self, n_mut: int, device: int = 0, dtype: str = "f64", workspace_bytes: int | None = None):
+    def __init__(self, n_mut: int, device: int | None = None, dtype: str = "f64", workspace_bytes: int | None = None):
         self.lib = _lib.load()
+        if device is None:
+            device = default_device()
+        self.device = int(device)
         self.n = int(n_mut)
         self.N = self.n + 1
         self.dtype = dtype
@@ -33,6 +57,7 @@ class Engine:
         _lib.check(self.lib.mmhn_create(int(device), self.n, F64 if dtype == "f64" else F32, C.byref(h)))
         self.h = h
         self.n_pat = 0
+        self.comm_size = 1
         if workspace_bytes:
             _lib.check(self.lib.mmhn_set_workspace_limit(self.h, int(workspace_bytes)))
 
@@ -146,6 +171,12 @@ class Engine:
                                                ddm.ctypes.data_as(f64p)))
         return ddp, ddm
 
+    def partial_diag_scal(self, log_d, state, p, i, which):
+        d, dp_ = _f(log_d); pv, pp = _f(p); st, sp = _s(state)
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_partial_diag_scal(self.h, dp_, sp, pp, int(i), int(which), y.ctypes.data_as(f64p)))
+        return y
+
     # ---- single-tumour primitives
     def v_kronvec(self, log_theta, p, state, diag=True, transpose=False):
         lt, ltp = _f(log_theta); pv, pp = _f(p); st, sp = _s(state)
@@ -174,6 +205,47 @@ class Engine:
                                                  dd.ctypes.data_as(f64p)))
         return G, dd
 
+    def v_kron_diag(self, log_theta, state, diag=None):
+        lt, ltp = _f(log_theta); st, sp = _s(state)
+        out = np.zeros(2 ** int(st.sum()))
+        dg = None
+        if diag is not None:
+            dkeep, dg = _f(diag)
+        _lib.check(self.lib.mmhn_v_kron_diag(self.h, ltp, sp, dg, out.ctypes.data_as(f64p)))
+        return out
+
+    def v_scal_d_pt(self, log_d_p, log_d_m, state, vec):
+        a, ap = _f(log_d_p); b, bp = _f(log_d_m); v, vp = _f(vec); st, sp = _s(state)
+        op, om = np.zeros_like(v), np.zeros_like(v)
+        _lib.check(self.lib.mmhn_v_scal_d_pt(self.h, ap, bp, sp, vp, op.ctypes.data_as(f64p), om.ctypes.data_as(f64p)))
+        return op, om
+
+    def v_d_scal_d_pt(self, log_d_p, log_d_m, state, vec, i):
+        a, ap = _f(log_d_p); b, bp = _f(log_d_m); v, vp = _f(vec); st, sp = _s(state)
+        op, om = np.zeros_like(v), np.zeros_like(v)
+        _lib.check(self.lib.mmhn_v_d_scal_d_pt(self.h, ap, bp, sp, vp, int(i), op.ctypes.data_as(f64p),
+                                               om.ctypes.data_as(f64p)))
+        return op, om
+
+    def v_x_partial_D_y(self, log_d_p, log_d_m, state, x, y):
+        a, ap = _f(log_d_p); b, bp = _f(log_d_m); xv, xp = _f(x); yv, yp = _f(y); st, sp = _s(state)
+        ddp, ddm = np.zeros(self.N), np.zeros(self.N)
+        _lib.check(self.lib.mmhn_v_x_partial_D_y(self.h, ap, bp, sp, xp, yp, ddp.ctypes.data_as(f64p),
+                                                 ddm.ctypes.data_as(f64p)))
+        return ddp, ddm
+
+    # ---- patient shards on several GPUs
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        """Join the RCCL communicator `unique_id` (from `unique_id()` on rank 0); afterwards cohort_sums / score /
+        score_and_grad return the sums over all ranks (one all-reduce on the engine's stream per call)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self.lib.mmhn_comm_init(self.h, buf, int(rank), int(n_ranks)))
+        self.comm_size = int(n_ranks)
+
+    def comm_destroy(self):
+        _lib.check(self.lib.mmhn_comm_destroy(self.h))
+        self.comm_size = 1
+
     # ---- simulation
     def simulate(self, log_theta, pt_d_ef, mt_d_ef, n_sim, seed=0, orders=False):
         """Gillespie samples: int8 dat [n_sim, 2n+2] (and the event sequences [n_sim, 2N+2] if `orders`)."""
@@ -194,10 +266,20 @@ class Engine:
                                                C.byref(ms)))
         return ms.value
 
+    def bench_stream(self, nbytes=1 << 30, iters=10, kind="copy"):
+        """Measured device-memory bandwidth (GB/s) of a plain copy / triad stream on this GPU."""
+        out = C.c_double()
+        _lib.check(self.lib.mmhn_bench_stream(self.h, int(nbytes), int(iters), 0 if kind == "copy" else 1, C.byref(out)))
+        return out.value
+
     def counters(self):
         c = _lib.Counters()
         _lib.check(self.lib.mmhn_get_counters(self.h, C.byref(c)))
-        return {k: getattr(c, k) for k, _ in c._fields_}
+        out = {"eval_ms": c.eval_ms, "evals": c.evals}
+        for i, name in enumerate(_lib.KERNEL_CLASSES):
+            k = c.kernel[i]
+            out[name] = {"ms": k.ms, "launches": k.launches, "alg_bytes": k.alg_bytes}
+        return out
 
     def reset_counters(self):
         _lib.check(self.lib.mmhn_reset_counters(self.h))

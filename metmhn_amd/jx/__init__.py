@@ -9,7 +9,8 @@ _ENG: dict = {}
 
 
 def engine(n_mut: int, dtype: str = "f64") -> Engine:
-    key = (n_mut, dtype)
+    from ..engine import default_device
+    key = (n_mut, dtype, default_device())
     if key not in _ENG:
         _ENG[key] = Engine(n_mut, dtype=dtype)
     return _ENG[key]

@@ -29,6 +29,16 @@ def diag_scal_m(log_d_m, state, p):
     return engine(n_from_joint(state)).diag_scal(log_d_m, state, p, 1)
 
 
+def partial_diag_scal_p(log_d_p, state, p, i: int):
+    """kronvec.py:632-644: (dD_p / dlog d_p[i]) * p."""
+    return engine(n_from_joint(state)).partial_diag_scal(log_d_p, state, p, i, 0)
+
+
+def partial_diag_scal_m(log_d_m, state, p, i: int):
+    """kronvec.py:704-710: (dD_m / dlog d_m[i]) * p."""
+    return engine(n_from_joint(state)).partial_diag_scal(log_d_m, state, p, i, 1)
+
+
 def obs_states(n_joint: int, state, pt_first: bool = True):
     """kronvec.py:1056-1095: 0/1 mask of the compatible joint states."""
     idx = engine(n_from_joint(state)).obs_indices(state, pt_first)

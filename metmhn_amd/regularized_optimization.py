@@ -25,8 +25,18 @@ _OPTIONS = {"device": None, "dtype": "f64", "shard": True}
 
 def configure(device: int | None = None, dtype: str = "f64", shard: bool = True):
     """Pick the GPU (default: LOCAL_RANK or 0), the engine dtype and whether to shard over ranks."""
+    from .engine import set_default_device
     _OPTIONS.update(device=device, dtype=dtype, shard=shard)
-    _CACHE.clear()
+    set_default_device(device)
+    invalidate()
+
+
+def invalidate(dat=None):
+    """Drop the cached device cohort of `dat` (all of them if None).  The cache recognises an array by identity
+    (object, buffer address, shape), not by content: call this after changing a cohort array IN PLACE."""
+    for key in list(_CACHE):
+        if dat is None or key[0] == id(dat):
+            _CACHE.pop(key)[0].close()
 
 
 def _rank_world():
@@ -39,28 +49,78 @@ def _rank_world():
     return 0, 1
 
 
+def _join_comm(eng: Engine, rank: int, world: int) -> bool:
+    """Attach the engine to an RCCL communicator over the ranks of the torch.distributed job (backend nccl): the
+    id travels through torch's object broadcast, the all-reduce itself then runs inside mmhn_cohort_sums on the
+    engine's stream.  False -> the caller keeps the host-staged torch all-reduce (gloo / CPU tests)."""
+    import os
+    import torch.distributed as dist
+    from .engine import unique_id
+    if world > 1 and dist.get_backend() != "nccl":
+        return False
+    try:
+        box = [unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0], rank, world)
+        return True
+    except Exception as exc:                                  # RCCL not loadable: keep torch's collective
+        if os.environ.get("MMHN_STRICT_COMM") == "1":
+            raise
+        import warnings
+        warnings.warn(f"metmhn_amd: in-library RCCL communicator unavailable ({exc}); using torch.distributed")
+        return False
+
+
+def _cache_key(dat, rank, world):
+    """Identity key of a cohort array (no pass over its bytes on the per-evaluation path)."""
+    if isinstance(dat, np.ndarray):
+        return (id(dat), dat.__array_interface__["data"][0], dat.shape, dat.dtype.str, rank, world, _OPTIONS["dtype"])
+    arr = np.ascontiguousarray(np.asarray(dat).astype(np.int8))          # lists, foreign array types: by content
+    return (None, zlib.crc32(arr.tobytes()), arr.shape, "i1", rank, world, _OPTIONS["dtype"])
+
+
 def _engine_for(dat) -> Engine:
     import os
-    dat = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+    import weakref
     rank, world = _rank_world()
     if not _OPTIONS["shard"]:
         rank, world = 0, 1
-    key = (dat.shape, zlib.crc32(dat.tobytes()), rank, world, _OPTIONS["dtype"])
-    eng = _CACHE.get(key)
-    if eng is None:
-        if len(_CACHE) >= _MAX_CACHE:
-            _CACHE.pop(next(iter(_CACHE))).close()
-        n_mut = (dat.shape[1] - 3) // 2
-        dev = _OPTIONS["device"]
-        if dev is None:
-            dev = int(os.environ.get("LOCAL_RANK", "0"))
-        eng = Engine(n_mut, device=dev, dtype=_OPTIONS["dtype"])
-        rows = dat if world == 1 else dat[_dist.shard_rows(dat, world)[rank]]
-        eng.set_cohort(rows)
-        # MMHN_FORCE_ALLREDUCE=1: run the collective even with one rank (exercises the RCCL path on a 1-GPU box)
-        eng._sharded = world > 1 or os.environ.get("MMHN_FORCE_ALLREDUCE") == "1"
-        _CACHE[key] = eng
+    key = _cache_key(dat, rank, world)
+    hit = _CACHE.get(key)
+    if hit is not None and (hit[1] is None or hit[1]() is dat):
+        return hit[0]
+    if hit is not None:                                       # the id was recycled for another array
+        _CACHE.pop(key)[0].close()
+    for k2 in [k2 for k2, (e2, r2) in _CACHE.items() if r2 is not None and r2() is None]:
+        _CACHE.pop(k2)[0].close()                             # cohorts whose array is gone free their HBM now
+    arr = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+    if len(_CACHE) >= _MAX_CACHE:
+        _CACHE.pop(next(iter(_CACHE)))[0].close()
+    n_mut = (arr.shape[1] - 3) // 2
+    eng = Engine(n_mut, device=_OPTIONS["device"], dtype=_OPTIONS["dtype"])
+    rows = arr if world == 1 else arr[_dist.shard_rows(arr, world)[rank]]
+    eng.set_cohort(rows)
+    # MMHN_FORCE_ALLREDUCE=1: run the collective even with one rank (exercises the RCCL path on a 1-GPU box)
+    eng._sharded = world > 1 or os.environ.get("MMHN_FORCE_ALLREDUCE") == "1"
+    eng._device_comm = eng._sharded and _join_comm(eng, rank, world)
+    ref = None
+    if isinstance(dat, np.ndarray):
+        try:
+            ref = weakref.ref(dat)
+        except TypeError:
+            ref = None
+    _CACHE[key] = (eng, ref)
     return eng
+
+
+def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool):
+    """Cohort-wide partial sums: this rank's shard, combined over the ranks by ONE all-reduce - inside the library
+    on the engine's stream (RCCL) when the communicator is attached, else through torch.distributed."""
+    sums = eng.cohort_sums(log_theta, log_d_p, log_d_m, with_grad=with_grad)
+    if eng._sharded and not eng._device_comm:
+        sums = _dist.allreduce_sums(sums)
+    return sums
 
 
 # ---- penalties (host NumPy, as in the reference; regularized_optimization.py:11-52) ----
@@ -107,18 +167,13 @@ def symmetric_penal(params, n_total: int, eps=1e-05):
 def score(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """Log-likelihood of the dataset (regularized_optimization.py:55-130)."""
     eng = _engine_for(dat)
-    sums = _dist.allreduce_sums(eng.cohort_sums(log_theta, log_d_p, log_d_m, with_grad=False)) \
-        if eng._sharded else eng.cohort_sums(log_theta, log_d_p, log_d_m, with_grad=False)
-    return _dist.combine_sums(sums, eng.N, perc_met)[0]
+    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, False), eng.N, perc_met)[0]
 
 
 def score_and_grad(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """(score, d_theta, d_d_p, d_d_m)  (regularized_optimization.py:163-267)."""
     eng = _engine_for(dat)
-    sums = eng.cohort_sums(log_theta, log_d_p, log_d_m, with_grad=True)
-    if eng._sharded:
-        sums = _dist.allreduce_sums(sums)
-    return _dist.combine_sums(sums, eng.N, perc_met)
+    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, True), eng.N, perc_met)
 
 
 def _unpack(params, n_total):

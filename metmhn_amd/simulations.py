@@ -13,9 +13,11 @@ _engines: dict = {}
 
 
 def _engine(n_mut: int) -> Engine:
-    if n_mut not in _engines:
-        _engines[n_mut] = Engine(n_mut)
-    return _engines[n_mut]
+    from .engine import default_device
+    key = (n_mut, default_device())
+    if key not in _engines:
+        _engines[key] = Engine(n_mut)
+    return _engines[key]
 
 
 def _seed(key) -> int:

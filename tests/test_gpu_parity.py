@@ -511,3 +511,259 @@ def test_per_patient_reference_entry_points(golden):
     np.testing.assert_allclose(d_th, gv["c4_grad_th"], **TIGHT)
     np.testing.assert_allclose(d_diag, gv["c4_grad_ddiag"], **TIGHT)
     np.testing.assert_allclose(pth, gv["c4_grad_pth"], **TIGHT)
+
+
+# ---- round 2: BASELINE configurations that had no parity test, new entry points, sharded engine ---------------------
+import os as _os
+
+GOLDEN = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+def test_config1_n12_1000_patients_both_schedules(monkeypatch):
+    """BASELINE configs[1] at full size: n = 12, 1 000 paired patients with k = 12 (one 2^12 tile each), fp64; every
+    patient's log-prob and gradient from both kernel schedules against oracle/metmhn_fast.c."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 12
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 1000, seed=2012)
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    for pmin in ("1", "1000000"):
+        monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
+        e = Engine(n)
+        e.set_cohort(dat)
+        r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], lp, rtol=1e-9, err_msg=f"lp pmin={pmin}")
+        np.testing.assert_allclose(r[1], g, rtol=1e-9, atol=1e-11, err_msg=f"d_theta pmin={pmin}")
+        np.testing.assert_allclose(r[2], a, rtol=1e-9, atol=1e-11, err_msg=f"d_dp pmin={pmin}")
+        np.testing.assert_allclose(r[3], b, rtol=1e-9, atol=1e-11, err_msg=f"d_dm pmin={pmin}")
+
+
+def test_config4_n25_fp32_against_fp64_cpu():
+    """BASELINE configs[4] dtype and size: n = k = 25 (2^25-state vectors, 128 MiB fp32 each), engine dtype f32, against
+    oracle/metmhn_fast.c in fp64.  fp32 bar (necessarily looser than 1e-6): log-prob 1e-4 relative, gradients
+    within 1e-2 of their norm.  Also one k = 22 patient: fp32 engine against the fp64 engine."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 25
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 3, seed=2025)
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    e = Engine(n, dtype="f32")
+    e.set_cohort(dat)
+    r = e.patient_grads(lt, dp, dm)
+    e.close()
+    assert np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1]))
+    np.testing.assert_allclose(r[0], lp, rtol=1e-4)
+    for x32, x64, nm in ((r[1], g, "d_theta"), (r[2], a, "d_dp"), (r[3], b, "d_dm")):
+        for i in range(dat.shape[0]):
+            assert np.linalg.norm(x32[i] - x64[i]) <= 1e-2 * np.linalg.norm(x64[i]), f"{nm} patient {i}"
+    n = 22
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 1, seed=2022)
+    res = []
+    for dt in ("f64", "f32"):
+        e = Engine(n, dtype=dt)
+        e.set_cohort(dat)
+        res.append(e.patient_grads(lt, dp, dm))
+        e.close()
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4)
+    for x32, x64 in zip(res[1][1:], res[0][1:]):
+        assert np.linalg.norm(x32 - x64) <= 1e-2 * np.linalg.norm(x64)
+
+
+def test_partial_diag_scal_golden(golden):
+    """kronvec.partial_diag_scal_p / _m (kronvec.py:605-710) for every event index."""
+    from metmhn_amd.jx import kronvec as K
+    g = golden("primitives")
+    seen = 0
+    for c in _cases(g):
+        pre = f"c{c}_"
+        if pre + "pdsp" not in g:
+            continue
+        st, p, dp, dm = g[pre + "state"], g[pre + "p"], g[pre + "log_d_p"], g[pre + "log_d_m"]
+        for i in range(dp.shape[0]):
+            np.testing.assert_allclose(K.partial_diag_scal_p(dp, st, p, i), g[pre + "pdsp"][i], **TIGHT)
+            np.testing.assert_allclose(K.partial_diag_scal_m(dm, st, p, i), g[pre + "pdsm"][i], **TIGHT)
+        seen += 1
+    assert seen >= 10
+
+
+def test_vanilla_observation_rate_primitives_golden(golden):
+    """vanilla.kron_diag, scal_d_pt, d_scal_d_pt, x_partial_D_y (vanilla.py:115-260) through their own entry points."""
+    from metmhn_amd.jx import vanilla as V
+    g = golden("vanilla")
+    seen = 0
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, st, p, x = g[pre + "log_theta"], g[pre + "state"], g[pre + "p"], g[pre + "x"]
+        np.testing.assert_allclose(V.kron_diag(lt, st, np.ones_like(p)), g[pre + "kron_diag"], **TIGHT)
+        np.testing.assert_allclose(V.kron_diag(lt, st, p), g[pre + "kron_diag"] * p, **TIGHT)
+        if pre + "scal_dp" not in g:
+            continue
+        dp, dm = g[pre + "log_d_p"], g[pre + "log_d_m"]
+        a, b = V.scal_d_pt(dp, dm, st, p)
+        np.testing.assert_allclose(a, g[pre + "scal_dp"], **TIGHT)
+        np.testing.assert_allclose(b, g[pre + "scal_dm"], **TIGHT)
+        a, b = V.x_partial_D_y(dp, dm, st, x, p)
+        np.testing.assert_allclose(a, g[pre + "xDy_dp"], **TIGHT)
+        np.testing.assert_allclose(b, g[pre + "xDy_dm"], **TIGHT)
+        if pre + "dscal_dp" in g:
+            for i in range(dp.shape[0]):
+                a, b = V.d_scal_d_pt(dp, dm, st, p, i)
+                np.testing.assert_allclose(a, g[pre + "dscal_dp"][i], **TIGHT)
+                np.testing.assert_allclose(b, g[pre + "dscal_dm"][i], **TIGHT)
+        seen += 1
+    assert seen >= 3
+
+
+def test_in_library_rccl_allreduce_single_rank(monkeypatch, golden):
+    """MMHN_FORCE_ALLREDUCE=1 with a 1-rank nccl group: Engine.cohort_sums -> k_pack_sums -> ncclAllReduce on the
+    engine's stream (mmhn_comm_init) -> combine_sums, against the reference's cohort golden."""
+    import torch
+    import torch.distributed as dist
+    import metmhn_amd.regularized_optimization as ro
+    monkeypatch.setenv("MMHN_FORCE_ALLREDUCE", "1")
+    monkeypatch.setenv("MMHN_STRICT_COMM", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ro.configure(device=0)
+        g = golden("cohorts")
+        for c in (0, 1):
+            pre = f"c{c}_"
+            dat = g[pre + "dat"]
+            s, gt, gp, gm = ro.score_and_grad(g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], dat, float(g[pre + "perc_met"]))
+            eng = ro._engine_for(dat)
+            assert eng._sharded and eng._device_comm
+            np.testing.assert_allclose(s, g[pre + "score"], rtol=1e-9)
+            np.testing.assert_allclose(gt, g[pre + "d_th"], **TIGHT)
+            np.testing.assert_allclose(gp, g[pre + "d_dp"], **TIGHT)
+            np.testing.assert_allclose(gm, g[pre + "d_dm"], **TIGHT)
+    finally:
+        ro.configure()
+        dist.destroy_process_group()
+
+
+def _shard_worker(rank, world, port, q):
+    """One rank of the sharded-engine test: real Engine on cuda:0 over its LPT shard; gloo carries the all-reduce
+    (two ranks cannot share one GPU under RCCL)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import metmhn_amd.regularized_optimization as ro
+    ro.configure(device=0)
+    g = np.load(os.path.join(root, "tests", "golden", "cohorts.npz"))
+    res = ro.score_and_grad(g["c1_log_theta"], g["c1_log_d_p"], g["c1_log_d_m"], g["c1_dat"], float(g["c1_perc_met"]))
+    eng = ro._engine_for(g["c1_dat"])
+    q.put((rank, eng.n_pat, [np.asarray(r) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_engine_matches_golden(golden):
+    """world_size 2, each rank a real engine over its own patient shard, one all-reduce: every rank gets the
+    unsharded (reference) result."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = golden("cohorts")
+    assert sorted(r[0] for r in got) == [0, 1]
+    assert sum(r[1] for r in got) == g["c1_dat"].shape[0] and all(r[1] > 0 for r in got)
+    for _, _, res in got:
+        np.testing.assert_allclose(res[0], g["c1_score"], rtol=1e-9)
+        np.testing.assert_allclose(res[1], g["c1_d_th"], **TIGHT)
+        np.testing.assert_allclose(res[2], g["c1_d_dp"], **TIGHT)
+        np.testing.assert_allclose(res[3], g["c1_d_dm"], **TIGHT)
+
+
+def test_engines_on_explicit_device_and_guard():
+    """Every ABI entry selects the engine's GPU itself (DevGuard) and restores the caller's device."""
+    import torch
+    from metmhn_amd import Engine, synthetic
+    n = 5
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.mixed_cohort(n, 20, seed=9)
+    e = Engine(n, device=0)
+    e.set_cohort(dat)
+    r0 = e.patient_grads(lt, dp, dm, with_grad=False)
+    assert torch.cuda.current_device() == 0
+    e2 = Engine(n)                      # default device: LOCAL_RANK or 0
+    e2.set_cohort(dat)
+    np.testing.assert_allclose(e2.patient_grads(lt, dp, dm, with_grad=False), r0, rtol=1e-13)
+    e.close(); e2.close()
+    with pytest.raises(RuntimeError):
+        Engine(n, device=10_000)
+
+
+def test_luad_reduced_anchor(golden):
+    """BASELINE configs[0] / SURVEY Appendix C.2: the 4 852 x 43 LUAD-reduced cohort at indep(dat), perc_met 0.2:
+    score = -8.43382859658627, and the reference's full gradient (fixture made by tests/tools/make_golden_luad.py)."""
+    import os
+    if not os.path.exists(os.path.join(GOLDEN, "luad_indep.npz")):
+        pytest.skip("luad_indep.npz not generated")
+    import metmhn_amd.regularized_optimization as ro
+    from metmhn_amd import Utilityfunctions as U
+    g = golden("luad_indep")
+    dat = g["dat"]
+    assert dat.shape == (4852, 43) and list(np.bincount(dat[:, -1])) == [595, 1677, 2127, 453]
+    th, dp, dm = U.indep(dat)
+    np.testing.assert_allclose(th, g["indep_theta"], rtol=1e-12)
+    s, gt, gp, gm = ro.score_and_grad(g["indep_theta"], g["indep_dp"], g["indep_dm"], dat, 0.2)
+    np.testing.assert_allclose(s, -8.43382859658627, rtol=1e-9)
+    np.testing.assert_allclose(s, g["indep_score"], rtol=1e-10)
+    np.testing.assert_allclose(np.linalg.norm(gt), 1.66178987553837, rtol=1e-8)
+    np.testing.assert_allclose(gt, g["indep_d_th"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gp, g["indep_d_dp"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gm, g["indep_d_dm"], rtol=1e-7, atol=1e-10)
+    params = np.concatenate((g["indep_theta"].flatten(), g["indep_dp"], g["indep_dm"]))
+    v, gr = ro.score_and_grad_reg(params, dat, 0.2, ro.symmetric_penal, 1e-3)
+    np.testing.assert_allclose(v, g["indep_reg_value"], rtol=1e-9)
+    np.testing.assert_allclose(gr, g["indep_reg_grad"], rtol=1e-7, atol=1e-10)
+
+
+def test_luad_fit_reaches_published_objective(golden):
+    """SURVEY 8f-1 "done": learn_mhn from indep(dat) with the reference's own settings (perc_met 0.2, lambda 1e-3,
+    ftol 1e-5; examples/data_analysis.ipynb) reaches the penalised objective of the parameters the reference
+    published (results/luad/luad_g14_20muts.csv, evaluated by the reference in luad_fit.npz)."""
+    import os
+    if not (os.path.exists(os.path.join(GOLDEN, "luad_indep.npz")) and os.path.exists(os.path.join(GOLDEN, "luad_fit.npz"))):
+        pytest.skip("LUAD fixtures not generated")
+    import metmhn_amd.regularized_optimization as ro
+    gi, gf = golden("luad_indep"), golden("luad_fit")
+    dat = gi["dat"]
+    # the engine agrees with the reference at the published parameters
+    pf = np.concatenate((gf["fit_theta"].flatten(), gf["fit_dp"], gf["fit_dm"]))
+    v_pub, g_pub = ro.score_and_grad_reg(pf, dat, 0.2, ro.symmetric_penal, 1e-3)
+    np.testing.assert_allclose(v_pub, gf["fit_reg_value"], rtol=1e-9)
+    np.testing.assert_allclose(g_pub, gf["fit_reg_grad"], rtol=1e-6, atol=1e-9)
+    th, dp, dm = ro.learn_mhn(gi["indep_theta"], gi["indep_dp"], gi["indep_dm"], dat, 0.2, ro.symmetric_penal, 1e-3,
+                              opt_ftol=1e-5, opt_v=False)
+    v_fit = float(ro.score_reg(np.concatenate((th.flatten(), dp, dm)), dat, 0.2, ro.symmetric_penal, 1e-3))
+    # same optimiser, same start, same objective: the optimum found is the published one up to L-BFGS-B's stopping rule
+    assert v_fit <= float(gf["fit_reg_value"]) + 1e-4 * abs(float(gf["fit_reg_value"]))
+    assert abs(v_fit - float(gf["fit_reg_value"])) <= 2e-3 * abs(float(gf["fit_reg_value"]))

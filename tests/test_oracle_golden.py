@@ -27,6 +27,9 @@ def test_primitives(golden):
         if st[-1] == 1:
             np.testing.assert_allclose(O.diag_scal_p(dp, st, p), g[pre + "dsp"], **TOL)
             np.testing.assert_allclose(O.diag_scal_m(dm, st, p), g[pre + "dsm"], **TOL)
+            for i in range(dp.shape[0]):                       # kronvec.py:605-710
+                np.testing.assert_allclose(O.partial_diag_scal_p(dp, st, p, i), g[pre + "pdsp"][i], **TOL)
+                np.testing.assert_allclose(O.partial_diag_scal_m(dm, st, p, i), g[pre + "pdsm"][i], **TOL)
             n_prim, n_met = int(st[::2].sum()), int(st[1::2].sum() + 1)
             for name, pf, ns in (("pf", True, n_met), ("mf", False, n_prim)):
                 assert np.array_equal(O.obs_states(k, st, pf), g[pre + "obs_" + name])
@@ -67,6 +70,10 @@ def test_vanilla(golden):
             a, b = O.v_x_partial_D_y(dp, dm, st, x, p)
             np.testing.assert_allclose(a, g[pre + "xDy_dp"], **TOL)
             np.testing.assert_allclose(b, g[pre + "xDy_dm"], **TOL)
+            for i in range(dp.shape[0]):                       # vanilla.py:179-187
+                a, b = O.v_d_scal_d_pt(dp, dm, st, p, i)
+                np.testing.assert_allclose(a, g[pre + "dscal_dp"][i], **TOL)
+                np.testing.assert_allclose(b, g[pre + "dscal_dm"][i], **TOL)
 
 
 def test_patients(golden):
@@ -160,3 +167,25 @@ def test_optimised_cpu_variant_matches_reference_structure_port():
             np.testing.assert_allclose(y, x, rtol=1e-11, atol=1e-13)
     with pytest.raises(ValueError):
         cref.fast_patients(lt, dp, dm, np.array([[1, 0] * n + [1, -99, 1]], dtype=np.int8))
+
+
+def test_c_ports_pinned_to_reference_golden(golden):
+    """oracle/metmhn_ref.c (reference pass structure) and oracle/metmhn_fast.c (gather formulation) - the checkers of
+    the random sweeps and of the full-size GPU tests - directly against the reference's own per-patient outputs
+    (tests/golden/patients.npz: every datapoint type / order, k = 1 and k = 2 spaces included)."""
+    from oracle import cref
+    g = golden("patients")
+    for c in _cases(g):
+        pre = f"c{c}_"
+        lt, dp, dm, dat = g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"], g[pre + "dat"]
+        lp, gth, gdp, gdm = cref.patients(lt, dp, dm, dat)
+        np.testing.assert_allclose(lp, g[pre + "lp_grad"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(gth, g[pre + "d_th"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gdp, g[pre + "d_dp"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gdm, g[pre + "d_dm"], rtol=1e-10, atol=1e-12)
+        paired = dat[:, -1] == 3
+        lp, gth, gdp, gdm = cref.fast_patients(lt, dp, dm, dat[paired])
+        np.testing.assert_allclose(lp, g[pre + "lp_grad"][paired], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(gth, g[pre + "d_th"][paired], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gdp, g[pre + "d_dp"][paired], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gdm, g[pre + "d_dm"][paired], rtol=1e-10, atol=1e-12)

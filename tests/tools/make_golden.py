@@ -79,6 +79,9 @@ def primitives():
         if st[-1] == 1:
             out[pre + "dsp"] = A(rk.diag_scal_p(J(dp), J(st), J(p)))
             out[pre + "dsm"] = A(rk.diag_scal_m(J(dm), J(st), J(p)))
+            # (dD/dlog d[i]) p for every event index (kronvec.py:632-644, :704-710)
+            out[pre + "pdsp"] = np.array([A(rk.partial_diag_scal_p(J(dp), J(st), J(p), i)) for i in range(n + 1)])
+            out[pre + "pdsm"] = np.array([A(rk.partial_diag_scal_m(J(dm), J(st), J(p), i)) for i in range(n + 1)])
             n_prim = int(st[::2].sum())
             n_met = int(st[1::2].sum() + 1)
             for name, pf, ns in (("pf", True, n_met), ("mf", False, n_prim)):
@@ -132,6 +135,9 @@ def vanilla():
             out[pre + "scal_dp"], out[pre + "scal_dm"] = A(a), A(b)
             a, b = rv.x_partial_D_y(J(dp), J(dm), J(st), J(x), J(p))
             out[pre + "xDy_dp"], out[pre + "xDy_dm"] = A(a), A(b)
+            ds = [rv.d_scal_d_pt(J(dp), J(dm), J(st), J(p), i) for i in range(n + 1)]      # vanilla.py:179-187
+            out[pre + "dscal_dp"] = np.array([A(t[0]) for t in ds])
+            out[pre + "dscal_dm"] = np.array([A(t[1]) for t in ds])
         c += 1
     out["n_cases"] = np.int64(c)
     np.savez_compressed(os.path.join(OUT, "vanilla.npz"), **out)
