@@ -102,6 +102,16 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(metmhn_amd has no CPU fallback)")
+    # PyTorch wheels bundle their own ROCm runtime (libamdhip64.so.7, libhsa-runtime64.so.1 under torch/lib).  A process
+    # must not end up with two HIP runtimes: if this library came first (bound to /opt/rocm's copy), a later
+    # `import torch` + torch.cuda / RCCL initialisation fails with "No HIP GPUs are available".  So when torch is
+    # installed it is imported first and both sides share its runtime (same sonames; the order bench.py always had).
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -189,3 +189,37 @@ def test_c_ports_pinned_to_reference_golden(golden):
         np.testing.assert_allclose(gth, g[pre + "d_th"][paired], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(gdp, g[pre + "d_dp"][paired], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(gdm, g[pre + "d_dm"][paired], rtol=1e-10, atol=1e-12)
+
+
+def _cohort_from_patients(lp, gt, gp, gm, dat, perc_met):
+    """regularized_optimization.py:121-130, :256-266 on per-patient results."""
+    em = dat[:, -1] != 0
+    n_em = float(dat[:, -3].sum())
+    n_nm = dat.shape[0] - n_em
+    w = perc_met * n_nm / ((1 - perc_met) * n_em) if n_em * n_nm != 0 else 1.0
+    nf = w * n_em + n_nm
+    return ((w * lp[em].sum() + lp[~em].sum()) / nf, (w * gt[em].sum(0) + gt[~em].sum(0)) / nf,
+            (w * gp[em].sum(0) + gp[~em].sum(0)) / nf, w * gm[em].sum(0) / nf)
+
+
+def test_luad_reduced_anchor_cpu(golden):
+    """BASELINE configs[0] / SURVEY Appendix C.2 on the host: the C port on the full 4 852-row LUAD-reduced cohort against
+    the reference's score and gradient at indep(dat) and at the published fit (tests/tools/make_golden_luad.py)."""
+    from oracle import cref
+    gi, gf = golden("luad_indep"), golden("luad_fit")
+    dat = gi["dat"]
+    assert dat.shape == (4852, 43) and list(np.bincount(dat[:, -1])) == [595, 1677, 2127, 453]
+    for g, pre in ((gi, "indep_"), (gf, "fit_")):
+        lt, dp, dm = g[pre + "theta"], g[pre + "dp"], g[pre + "dm"]
+        s, G, a, b = _cohort_from_patients(*cref.patients(lt, dp, dm, dat), dat, float(g["perc_met"]))
+        np.testing.assert_allclose(s, g[pre + "score"], rtol=1e-12)
+        np.testing.assert_allclose(G, g[pre + "d_th"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(a, g[pre + "d_dp"], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(b, g[pre + "d_dm"], rtol=1e-9, atol=1e-13)
+        params = np.concatenate((lt.flatten(), dp, dm))
+        pen, pen_ = O.symmetric_penal(params, lt.shape[0])
+        np.testing.assert_allclose(-s + float(g["lam"]) * pen, g[pre + "reg_value"], rtol=1e-12)
+    np.testing.assert_allclose(float(gi["indep_score"]), -8.43382859658627, rtol=1e-13)      # SURVEY Appendix C.2
+    np.testing.assert_allclose(np.linalg.norm(gi["indep_d_th"]), 1.66178987553837, rtol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(gi["indep_d_dp"]), 0.4435122531351038, rtol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(gi["indep_d_dm"]), 0.03620795819315152, rtol=1e-12)
