@@ -278,6 +278,7 @@ struct Engine : EngineBase {
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
+  int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   // counters
   mmhn_counters cnt{};
@@ -317,6 +318,7 @@ struct Engine : EngineBase {
       use_jacobi = sv && std::string(sv) == "jacobi";
       if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) psolve_min = std::atoi(pm);
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
+      if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -324,6 +326,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -492,10 +496,25 @@ struct Engine : EngineBase {
     const long long spare = (80 * 1024 - 64) - (long long)psolve_lds(maxk);
     return (int)std::max<long long>(0, std::min<long long>(PS_DL, spare / (long long)sizeof(T)));
   }
+  // k_psolve2 (all-seeded-tile launches): no popcount permutation of the tile in LDS
+  size_t psolve2_lds(int maxk) const {
+    return DESC_PAD + ((size_t)(1 << TB) + (size_t)((1 << TB) / TSB) + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (size_t)TSB * sizeof(uint16_t);
+  }
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
     const int mk = std::max(b.maxkJ, 1);
+    if (b.all_multi && psolve_version == 2) {
+      const long long spare = (80 * 1024 - 64) - (long long)psolve2_lds(mk);
+      const int dl_cap = (int)std::max<long long>(0, std::min<long long>(PS_DL2, spare / (long long)sizeof(T)));
+      const size_t lds = psolve2_lds(mk) + (size_t)dl_cap * sizeof(T);
+      const double bytes = (double)b.ptiles.size() * (double)(1 << TB) * sizeof(T);
+      timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
+        if (tr) hipLaunchKernelGGL((k_psolve2<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
+        else hipLaunchKernelGGL((k_psolve2<T, false>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
+      });
+      return;
+    }
     const int dl_cap = psolve_dl_cap(mk);
     const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once

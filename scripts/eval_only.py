@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Two evaluations of the bench cohort and nothing else: the command the PMC passes of scripts/pmc_eval.sh profile.
+    python scripts/eval_only.py [patients=5000] [n=20] [dtype=f64]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metmhn_amd import Engine, synthetic
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+lt, dp, dm = synthetic.random_params(n)
+dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
+e = Engine(n, dtype=sys.argv[3] if len(sys.argv) > 3 else "f64")
+e.set_cohort(dat)
+for _ in range(2):
+    s = e.cohort_sums(lt, dp, dm)
+print(s[0])
