@@ -29,6 +29,7 @@
 
 #include "../../include/metmhn_amd.h"
 #include "kernels.h"
+#include "small.h"
 #include "sampler.h"
 
 namespace mmhn {
@@ -96,6 +97,10 @@ struct Batch {
   std::vector<int2> mapX;
   DevArr<int2> d_mapX;
   DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
+  // small-space path (small.h): patients by size class of their largest single-tumour space; sp_ok: every one fits a tile
+  std::vector<int> sp_list[SP_NCLASS];
+  DevArr<int> d_sp_list[SP_NCLASS];
+  bool sp_ok = false;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   std::vector<int> ptoff;
   std::vector<uint32_t> ptiles;
@@ -258,7 +263,7 @@ struct Engine : EngineBase {
   int n = 0, N = 0;
   size_t ws_limit = 0;
   DevArr<Params<T>> d_par;
-  std::vector<Params<T>> h_par;
+  Params<T>* h_par = nullptr;         // pinned: the per-evaluation upload is a true async copy
   // cohort
   std::vector<int8_t> dat;
   long long n_pat = 0;
@@ -278,6 +283,9 @@ struct Engine : EngineBase {
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
+  hipStream_t side[SP_NCLASS - 1] = {};   // side streams of the small-space path (size classes run side by side)
+  hipEvent_t ev_fork = nullptr, ev_join[SP_NCLASS - 1] = {};
+  bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   // counters
@@ -293,7 +301,7 @@ struct Engine : EngineBase {
     DevGuard guard(device);
     HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     d_par.alloc(NPSET);
-    h_par.resize(NPSET);
+    HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_par), NPSET * sizeof(Params<T>), hipHostMallocDefault));
     sums.alloc(2 * stride());
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
@@ -319,6 +327,7 @@ struct Engine : EngineBase {
       if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) psolve_min = std::atoi(pm);
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
+      if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -326,6 +335,14 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 64, SP_PPB0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int i = 0; i < SP_NCLASS - 1; ++i) {
+      HIPCHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -347,6 +364,12 @@ struct Engine : EngineBase {
   ~Engine() override {                       // runs under the DevGuard of mmhn_destroy
     comm_destroy();
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int i = 0; i < SP_NCLASS - 1; ++i) {
+      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (h_par) (void)hipHostFree(h_par);
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -374,7 +397,7 @@ struct Engine : EngineBase {
         P.dm[i] = (T)std::exp(ldm[i]);
       }
     }
-    HIPCHECK(hipMemcpyAsync(d_par.p, h_par.data(), NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(d_par.p, h_par, NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
   }
 
   // ---------------------------------------------------------------- launches
@@ -735,6 +758,35 @@ struct Engine : EngineBase {
         }
       }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
+      b.sp_ok = !b.dS.empty();
+      for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[c].clear();
+      for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) {
+        const PatRec& pr = b.pats[pi_];
+        int ks = -1;
+        for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) ks = std::max(ks, b.dS[pr.s[part]].k);
+        if (ks < 0) continue;
+        if (ks > TB) { b.sp_ok = false; break; }
+        int c = 0;
+        while (ks > spatient_class_maxk(c)) ++c;
+        b.sp_list[c].push_back((int)pi_);
+      }
+      {
+        // largest spaces first: the waves of one workgroup (class 0: one patient each) then finish together and the
+        // long patients do not form the tail of the launch
+        auto ksize = [&](int pi_) {
+          const PatRec& pr = b.pats[pi_];
+          int ks = 0;
+          for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) ks = std::max(ks, 64 * b.dS[pr.s[part]].k + (pr.s[0] >= 0 && pr.s[1] >= 0 ? 32 : 0) + pr.kind);
+          return ks;
+        };
+        for (int c = 0; c < SP_NCLASS; ++c)
+          std::stable_sort(b.sp_list[c].begin(), b.sp_list[c].end(), [&](int x, int y) { return ksize(x) > ksize(y); });
+      }
+      for (int c = 0; c < SP_NCLASS; ++c) {
+        const size_t need_c = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (c <= 1 ? SP_PPB0 : 1);
+        if (!b.sp_list[c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
+        up(b.d_sp_list[c], b.sp_list[c]);
+      }
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles); up(b.d_mapX, b.mapX);
@@ -779,8 +831,9 @@ struct Engine : EngineBase {
       const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
       const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};
       const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS, tabS.p};
+      const bool fused_small = small_path && !use_jacobi && nS > 0 && b.sp_ok;
       prep(b.d_dJ.p, nJ, tabJ.p);
-      prep(b.d_dS.p, nS, tabS.p);
+      if (!fused_small) prep(b.d_dS.p, nS, tabS.p);        // (k_spatient builds its own tables in LDS)
       const bool per_patient = !use_jacobi && nJ >= psolve_min;
       // the tile-level substitution solver skips dead tiles and its consumers read them: those parts of pi / q_J
       // must hold zeros.  The per-patient kernels never let a value of a dead tile into arithmetic (they are only
@@ -802,28 +855,62 @@ struct Engine : EngineBase {
       if (per_patient) psolve(false, b, pi.p, 2);
       else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
       // 3 marginal right-hand sides
-      zero(rhsS.p, b.vecS);
+      // small-space path (small.h): every single-tumour space of the batch fits one tile -> one launch does stage 4,
+      // the adjoint seeds, the single-tumour gradients and the <q, rhs> dots, one workgroup per patient
+      if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ) {
-        hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, 8), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
+        hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
                            b.d_dS.p, d_par.p, pi.p, rhsS.p);
         HIPCHECK(hipGetLastError());
       }
-      fill_e0(b);
-      // 4 single-tumour spaces
-      launch_diag(b.d_dS.p, b.d_mapS.p, tS, nullptr, lidgS.p, nullptr, KD_LIDG);
-      solve(false, LS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
-      hipLaunchKernelGGL((k_seeds<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
-                         d_par.p, pS.p, seedS.p, lp.p);
-      HIPCHECK(hipGetLastError());
-      if (grad) {
-        solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
-        zero(GS.p, (long long)nS * N * N);
-        launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grc[GK_S]);
-        if (b.has_kind2) {
-          zero(bmS.p, (long long)nS * 64);
-          hipLaunchKernelGGL((k_bit_marg<T>), dim3(tS), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapS.p, d_par.p,
-                             pS.p, qS.p, bmS.p);
+      if (fused_small) {
+        // the size classes are independent.  Measured on the LUAD-reduced cohort (three kernels run side by side, a
+        // fourth stream waits): classes 1 (k 5-6) and 3 (k 10-12) go to side streams, classes 0 (k <= 4) and 2 (k 7-9)
+        // follow each other on the main stream - about equal spans
+        int forked = 0;
+        const int order[SP_NCLASS] = {3, 1, 0, 2};
+        for (int oi = 0; oi < SP_NCLASS; ++oi) {
+          const int c = order[oi];
+          const int cnt_c = (int)b.sp_list[c].size(), mk = spatient_class_maxk(c);
+          if (cnt_c == 0) continue;
+          hipStream_t st = stream;
+          if (c == 1 || c == 3) {
+            if (!forked) HIPCHECK(hipEventRecord(ev_fork, stream));
+            st = side[c - 1];
+            HIPCHECK(hipStreamWaitEvent(st, ev_fork, 0));
+            forked |= 1 << c;
+          }
+          const size_t slice = (spatient_lds<T>(N, mk) + 15) / 16 * 16;
+#define SP_ARGS(threads, ppb) dim3((cnt_c + (ppb) - 1) / (ppb)), dim3((threads) * (ppb)), slice * (ppb), st, b.d_sp_list[c].p, cnt_c, b.d_pats.p, \
+                b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, rhsS.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p, mk, N, grad ? 1 : 0
+          if (c <= 1) hipLaunchKernelGGL((k_spatient<T, 64, SP_PPB0>), SP_ARGS(64, SP_PPB0));
+          else if (c == 2) hipLaunchKernelGGL((k_spatient<T, 256, 1>), SP_ARGS(256, 1));
+          else hipLaunchKernelGGL((k_spatient<T, 1024, 1>), SP_ARGS(1024, 1));
+#undef SP_ARGS
           HIPCHECK(hipGetLastError());
+          if (st != stream) HIPCHECK(hipEventRecord(ev_join[c - 1], st));
+        }
+        for (int c = 1; c < SP_NCLASS; ++c) if (forked & (1 << c)) HIPCHECK(hipStreamWaitEvent(stream, ev_join[c - 1], 0));
+      } else {
+        fill_e0(b);
+        // 4 single-tumour spaces
+        launch_diag(b.d_dS.p, b.d_mapS.p, tS, nullptr, lidgS.p, nullptr, KD_LIDG);
+        solve(false, LS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
+        hipLaunchKernelGGL((k_seeds<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
+                           d_par.p, pS.p, seedS.p, lp.p);
+        HIPCHECK(hipGetLastError());
+      }
+      if (grad) {
+        if (!fused_small) {
+          solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
+          zero(GS.p, (long long)nS * N * N);
+          launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grc[GK_S]);
+          if (b.has_kind2) {
+            zero(bmS.p, (long long)nS * 64);
+            hipLaunchKernelGGL((k_bit_marg<T>), dim3(tS), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapS.p, d_par.p,
+                               pS.p, qS.p, bmS.p);
+            HIPCHECK(hipGetLastError());
+          }
         }
         if (nJ) {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
@@ -831,7 +918,7 @@ struct Engine : EngineBase {
                              b.d_dS.p, d_par.p, links.p);
           HIPCHECK(hipGetLastError());
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
-          for (int part = 0; part < 2; ++part) {
+          for (int part = 0; part < 2 && !fused_small; ++part) {
             hipLaunchKernelGGL((k_scatter_marg<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
                                b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part);
             HIPCHECK(hipGetLastError());

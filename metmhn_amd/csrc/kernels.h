@@ -1714,19 +1714,24 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
                                                        const Desc* __restrict__ dS,
                                                        const Params<T>* __restrict__ par,
                                                        const T* __restrict__ pi, T* rhsS) {
+  __shared__ Desc djs;                                     // (the descriptor loops below must not be chains of global loads)
   const PatRec pr = pats[blockIdx.x];
   const int part = blockIdx.y;
-  if (pr.j < 0 || pr.s[part] < 0) return;
-  const Desc& dj = dJ[pr.j];
-  const Desc& ds = dS[pr.s[part]];
+  const int sp = part == 0 ? pr.s[0] : pr.s[1];
+  if (pr.j < 0 || sp < 0) return;
+  load_desc(&djs, dJ + pr.j);
+  const int ksS = dS[sp].k;
+  const long long offS = dS[sp].off;
+  __syncthreads();
+  const Desc& dj = djs;
   const uint32_t fixed = (part == 0 ? dj.maskP : dj.maskM) | (1u << dj.seedbit);
   const uint32_t free_ = part == 0 ? dj.maskM : dj.maskP;
-  const uint32_t half = 1u << (ds.k - 1);
+  const uint32_t half = 1u << (ksS - 1);
   const T c = obs_const(dj, par[PS_THETA], part);
   for (uint32_t e = blockIdx.z * BLOCK + threadIdx.x; e < half; e += gridDim.z * BLOCK) {
     const uint32_t x = pdep32(e, free_) | fixed;
-    rhsS[ds.off + e] = 0;
-    rhsS[ds.off + half + e] = c * pi[dj.off + x];
+    rhsS[offS + e] = 0;
+    rhsS[offS + half + e] = c * pi[dj.off + x];
   }
 }
 

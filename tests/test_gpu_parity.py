@@ -747,16 +747,18 @@ def test_luad_reduced_anchor(golden):
 
 
 def test_luad_fit_reaches_published_objective(golden):
-    """SURVEY 8f-1 "done": learn_mhn from indep(dat) with the reference's own settings (perc_met 0.2, lambda 1e-3,
-    ftol 1e-5; examples/data_analysis.ipynb) reaches the penalised objective of the parameters the reference
-    published (results/luad/luad_g14_20muts.csv, evaluated by the reference in luad_fit.npz)."""
+    """learn_mhn from indep(dat) with the reference's own LUAD settings (perc_met 0.2, lambda 1e-3,
+    ftol 1e-5; examples/data_analysis.ipynb cell 14).  The engine's objective equals the reference's at the published
+    parameters (results/luad/luad_g14_20muts.csv, evaluated by the reference in luad_fit.npz).  Those parameters are
+    NOT the optimum of that objective: SciPy's L-BFGS-B on the CPU oracle (oracle/metmhn_ref.c) goes from the same
+    start to 5.47856 in 48 iterations against 5.94956 at the published point - so the engine's fit must do at least
+    as well as the published point and land where the CPU optimiser lands."""
     import os
     if not (os.path.exists(os.path.join(GOLDEN, "luad_indep.npz")) and os.path.exists(os.path.join(GOLDEN, "luad_fit.npz"))):
         pytest.skip("LUAD fixtures not generated")
     import metmhn_amd.regularized_optimization as ro
     gi, gf = golden("luad_indep"), golden("luad_fit")
     dat = gi["dat"]
-    # the engine agrees with the reference at the published parameters
     pf = np.concatenate((gf["fit_theta"].flatten(), gf["fit_dp"], gf["fit_dm"]))
     v_pub, g_pub = ro.score_and_grad_reg(pf, dat, 0.2, ro.symmetric_penal, 1e-3)
     np.testing.assert_allclose(v_pub, gf["fit_reg_value"], rtol=1e-9)
@@ -764,6 +766,27 @@ def test_luad_fit_reaches_published_objective(golden):
     th, dp, dm = ro.learn_mhn(gi["indep_theta"], gi["indep_dp"], gi["indep_dm"], dat, 0.2, ro.symmetric_penal, 1e-3,
                               opt_ftol=1e-5, opt_v=False)
     v_fit = float(ro.score_reg(np.concatenate((th.flatten(), dp, dm)), dat, 0.2, ro.symmetric_penal, 1e-3))
-    # same optimiser, same start, same objective: the optimum found is the published one up to L-BFGS-B's stopping rule
-    assert v_fit <= float(gf["fit_reg_value"]) + 1e-4 * abs(float(gf["fit_reg_value"]))
-    assert abs(v_fit - float(gf["fit_reg_value"])) <= 2e-3 * abs(float(gf["fit_reg_value"]))
+    assert v_fit < float(gf["fit_reg_value"])
+    CPU_OPTIMUM = 5.47856203029577          # same optimiser, start and settings on the CPU oracle (48 iterations)
+    assert abs(v_fit - CPU_OPTIMUM) <= 2e-3 * CPU_OPTIMUM
+
+
+def test_staged_and_fused_small_paths_agree(monkeypatch, golden):
+    """The small-space path (csrc/small.h: one workgroup per patient) and the staged kernels it replaces, on the mixed
+    golden cohorts: both against the reference's values."""
+    from metmhn_amd import Engine, distributed as D
+    g = golden("cohorts")
+    for small in ("1", "0"):
+        monkeypatch.setenv("MMHN_SMALL", small)
+        for c in (0, 1, 3):
+            pre = f"c{c}_"
+            dat = g[pre + "dat"]
+            e = Engine((dat.shape[1] - 3) // 2)
+            e.set_cohort(dat)
+            s, gt, gp, gm = D.combine_sums(e.cohort_sums(g[pre + "log_theta"], g[pre + "log_d_p"], g[pre + "log_d_m"]),
+                                           g[pre + "log_theta"].shape[0], float(g[pre + "perc_met"]))
+            e.close()
+            np.testing.assert_allclose(s, g[pre + "score"], rtol=1e-9, err_msg=f"small={small} cohort {c}")
+            np.testing.assert_allclose(gt, g[pre + "d_th"], **TIGHT)
+            np.testing.assert_allclose(gp, g[pre + "d_dp"], **TIGHT)
+            np.testing.assert_allclose(gm, g[pre + "d_dm"], **TIGHT)
