@@ -285,6 +285,7 @@ struct Engine : EngineBase {
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
   hipStream_t side[SP_NCLASS - 1] = {};   // side streams of the small-space path (size classes run side by side)
   hipEvent_t ev_fork = nullptr, ev_join[SP_NCLASS - 1] = {};
+  int kv_version = 2;           // MMHN_KV=1: the round-1 kronvec kernel (k_sweep) also for plain products on multi-tile spaces
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
@@ -328,6 +329,7 @@ struct Engine : EngineBase {
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
+      if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
     }
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -349,6 +351,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, true>),
@@ -436,6 +440,14 @@ struct Engine : EngineBase {
                          lidg, rhs, rhs_mode, scal, std::max(maxk, 1), tab);
     HIPCHECK(hipGetLastError());
     if (timed) HIPCHECK(hipEventRecord(e1, stream));
+  }
+  // plain product on full tiles of multi-tile spaces (k_kv); hxt from k_hx for the same map
+  void launch_kv(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, const T* p, T* y, const T* tab, const T* hxt) {
+    if (ntiles == 0) return;
+    const size_t lds = DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)maxk * 64 + 32) * sizeof(T);
+    if (tr) hipLaunchKernelGGL((k_kv<T, true, 1>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, ntiles, p, y, tab, hxt, maxk);
+    else hipLaunchKernelGGL((k_kv<T, false, 1>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, ntiles, p, y, tab, hxt, maxk);
+    HIPCHECK(hipGetLastError());
   }
   void collect_events() {
     for (size_t i = 0; i < ev_used; ++i) {
@@ -1055,7 +1067,22 @@ struct Engine : EngineBase {
     const size_t V = (size_t)1 << d.k;
     up(m.a, p, V);
     m.b.alloc(V);
-    launch_sweep(tr, m.dd.p, m.map.p, m.ntiles, d.k, m.a.p, m.b.p, nullptr, nullptr, 0, nullptr, 0, m.tab.p);
+    if (d.k > TB && kv_version == 2) {
+      std::vector<int2> live;
+      for (int tl = 0; tl < m.ntiles; ++tl) if (!dead_tile(m.d, (uint32_t)tl)) live.push_back(make_int2(0, tl));
+      DevArr<int2> dlive;
+      DevArr<T> hxt;
+      dlive.alloc(live.size());
+      hxt.alloc(live.size() * (size_t)d.k);
+      HIPCHECK(hipMemcpyAsync(dlive.p, live.data(), live.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+      HIPCHECK(hipMemsetAsync(m.b.p, 0, V * sizeof(T), stream));      // structurally zero tiles are not launched
+      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)live.size()), dim3(64), 0, stream, m.dd.p, dlive.p, m.tab.p, hxt.p, d.k);
+      HIPCHECK(hipGetLastError());
+      launch_kv(tr, m.dd.p, dlive.p, (int)live.size(), d.k, m.a.p, m.b.p, m.tab.p, hxt.p);
+      HIPCHECK(hipStreamSynchronize(stream));
+    } else {
+      launch_sweep(tr, m.dd.p, m.map.p, m.ntiles, d.k, m.a.p, m.b.p, nullptr, nullptr, 0, nullptr, 0, m.tab.p);
+    }
     if (diag) launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, KD_ADDQP);
     down(y, m.b.p, V);
   }
@@ -1214,9 +1241,28 @@ struct Engine : EngineBase {
       launch_diag(dd.p, dm.p, (int)mp.size(), nullptr, c.p, nullptr, KD_LIDG);
       HIPCHECK(hipMemcpyAsync(r.p, a.p, (size_t)(batch * V) * sizeof(T), hipMemcpyDeviceToDevice, stream));
     }
+    // plain products on multi-tile spaces: the structurally zero tiles (seed = 0, no PT == MT state: Q_off and
+    // Q_off^T have no entries there) are neither read nor written - y is cleared once and only the live tiles are
+    // launched, as the engine's solves do
+    DevArr<T> hxt;
+    DevArr<int2> dlive;
+    const bool use_kv = !jacobi && d0.k > TB && kv_version == 2;
+    int nlive = 0;
+    if (use_kv) {
+      std::vector<int2> live;
+      for (const int2& m : mp) if (!dead_tile(ds[m.x], (uint32_t)m.y)) live.push_back(m);
+      nlive = (int)live.size();
+      dlive.alloc(live.size());
+      HIPCHECK(hipMemcpy(dlive.p, live.data(), live.size() * sizeof(int2), hipMemcpyHostToDevice));
+      HIPCHECK(hipMemsetAsync(b.p, 0, (size_t)(batch * V) * sizeof(T), stream));
+      hxt.alloc(live.size() * (size_t)d0.k);
+      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)nlive), dim3(64), 0, stream, dd.p, dlive.p, tb.p, hxt.p, d0.k);
+      HIPCHECK(hipGetLastError());
+    }
     auto run = [&]() {
-      launch_sweep(tr, dd.p, dm.p, (int)mp.size(), d0.k, a.p, b.p, jacobi ? c.p : nullptr, jacobi ? r.p : nullptr, 0,
-                   nullptr, 0, tb.p);
+      if (use_kv) launch_kv(tr, dd.p, dlive.p, nlive, d0.k, a.p, b.p, tb.p, hxt.p);
+      else launch_sweep(tr, dd.p, dm.p, (int)mp.size(), d0.k, a.p, b.p, jacobi ? c.p : nullptr, jacobi ? r.p : nullptr, 0,
+                        nullptr, 0, tb.p);
     };
     run(); run();
     hipEvent_t e0, e1;

@@ -447,6 +447,244 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
 }
 
 // ------------------------------------------------------------------------------------
+// k_kv: y = Q_off p (TR: Q_off^T p) on full tiles of multi-tile spaces - the kronvec metric (kronvec.py:499-539 with
+// diag = False).  Same arithmetic as k_sweep; what changed is the workgroup's schedule: the descriptor is read
+// through uniform (scalar) loads instead of an LDS copy behind a barrier, the tile-bit factors hx[b] of every tile come
+// from a table (k_hx, once per parameter set) and are folded into the per-lane factor instead of a rebuilt Utab behind
+// two more barriers, the tile and the tables share ONE barrier, and the first neighbour tiles are in flight while the
+// lane- and row-bit terms run from LDS.  Three barriers per tile instead of seven.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int sgpr(int v);
+__device__ __forceinline__ uint32_t sgpr(uint32_t v);
+__device__ __forceinline__ long long sgpr64(long long v);
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const int2* __restrict__ map,
+                                           const T* __restrict__ tab, T* __restrict__ hxt, int maxk) {
+  const Desc& d = descs[map[blockIdx.x].x];
+  const uint32_t H = (uint32_t)map[blockIdx.x].y;
+  const int k = d.k, t = k < TB ? k : TB, b = threadIdx.x;
+  if (b >= k) return;
+  const T* thc = tab + d.toff;
+  T h = thc[b * k + b];
+  for (int bb = t; bb < k; ++bb) if (bb != b && ((H >> (bb - t)) & 1u)) h *= thc[b * k + bb];
+  hxt[(long long)blockIdx.x * maxk + b] = h;
+}
+
+#ifndef MMHN_KV_PRE
+#define MMHN_KV_PRE 1          // neighbour tiles k_kv fetches ahead of its LDS terms
+#endif
+#ifndef MMHN_KV_WPS
+#define MMHN_KV_WPS 4          // waves per SIMD k_kv's registers are sized for (4: two 512-thread workgroups per CU, 128 VGPRs)
+#endif
+template <typename T, bool TR, int TPW>
+__global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict__ descs, const int2* __restrict__ map, int ntiles,
+                                                         const T* __restrict__ p, T* __restrict__ y,
+                                                         const T* __restrict__ tab, const T* __restrict__ hxt, int maxk) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Desc& dsh = *reinterpret_cast<Desc*>(smem);              // only staged for the generic path
+  T* tile = reinterpret_cast<T*>(smem + DESC_PAD);
+  T* Ltab = tile + (1 << TB);
+  T* Urow = Ltab + maxk * 64;
+  T* hx = Urow + maxk * 64;
+  const int tid = threadIdx.x;
+  constexpr int t = TB;
+  constexpr uint32_t nelem = 1u << TB, tmask = nelem - 1;
+  constexpr int NW = KSB / 64, NJ = 64 / NW;
+  const int wave = tid >> 6, lane = tid & 63;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PER = 16 / sizeof(T);
+  // a workgroup walks TPW consecutive tiles of the list (XCD-chunked): the tables of a problem are staged once per
+  // run, and the next tile's own states are fetched while the current tile computes.  (Measured: the walk costs more
+  // scalar and vector registers than it hides latency - TPW = 2 spills at 128 VGPRs - so TPW = 1 is what ships.)
+  constexpr int tpw = TPW;
+  const uint32_t first = xcd_chunked(blockIdx.x, gridDim.x) * (uint32_t)tpw;
+  int cur_prob = -1;
+  T vnext[NJ];
+  {
+    const int prob0 = sgpr(map[first].x);
+    const uint32_t H0 = sgpr((uint32_t)map[first].y);
+    const long long base0 = sgpr64(descs[prob0].off);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) vnext[j] = (p + base0 + (H0 << t))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
+  }
+#pragma unroll
+  for (int it = 0; it < tpw; ++it) {
+    const uint32_t blk = first + (uint32_t)it;
+    if (blk >= (uint32_t)ntiles) break;
+    const int prob = sgpr(map[blk].x);
+    const uint32_t H = sgpr((uint32_t)map[blk].y);
+    const Desc& dg = descs[prob];
+    const int k = sgpr(dg.k);
+    const long long base = sgpr64(dg.off), toff = sgpr64(dg.toff);
+    const uint32_t xhi = H << t;
+    const int seedb = sgpr(dg.seedbit);
+    const uint32_t lone = sgpr(dg.lone), pairP = sgpr(dg.pairP);
+    const bool joint = sgpr(dg.mode) == JOINT;
+    int kind = 0;                                             // tile_kind on scalars
+    if (joint) {
+      if (seedb < t) kind = 2;
+      else if (xhi & (1u << seedb)) kind = 0;
+      else {
+        const uint32_t hmask = ~tmask;
+        const uint32_t pp = pairP & hmask & 0x7fffffffu;
+        kind = ((xhi & lone & hmask) || (((xhi & pp) << 1) != (xhi & (pp << 1)))) ? 1 : 2;
+      }
+    }
+    T v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[j] = vnext[j];
+    if (it + 1 < tpw && blk + 1 < (uint32_t)ntiles) {          // next tile's own states: in flight during this tile
+      const int probn = sgpr(map[blk + 1].x);
+      const uint32_t Hn = sgpr((uint32_t)map[blk + 1].y);
+      const long long basen = sgpr64(descs[probn].off);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) vnext[j] = (p + basen + (Hn << t))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
+    }
+    if (kind == 1) {                                           // Q_off has no entries in this tile
+      for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
+        T* dst = y + base + xhi + e;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(zero4) : "memory");
+      }
+      continue;
+    }
+    // tables (once per problem), tile-bit factors and the tile: one barrier
+    if (prob != cur_prob) {
+      const T* src = tab + toff + k * k;
+      for (int e = tid; e < k * 64; e += KSB) { Ltab[e] = src[e]; Urow[e] = src[k * 64 + e]; }
+      cur_prob = prob;
+    }
+    if (tid < k) hx[tid] = hxt[(long long)blk * maxk + tid];
+    if (kind == 2) {
+      const int* sw = reinterpret_cast<const int*>(&dg);
+      int* dw = reinterpret_cast<int*>(&dsh);
+      for (int i = tid; i < DESC_WORDS; i += KSB) dw[i] = sw[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tile[((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane] = v[j];
+    __syncthreads();
+
+    T acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0;
+    if (kind == 0) {
+      // tile bits first: their neighbour rows come from other tiles (L2 / HBM) and fly while the LDS terms run
+      uint32_t mvs = 0;
+      for (int b = t; b < k; ++b) {
+        const uint32_t bit = 1u << b;
+        const bool has = (xhi & bit) != 0;
+        const bool is_seed = joint && b == seedb;
+        if (is_seed ? TR : (TR ? has : !has)) continue;       // seeding enters these tiles only in Q (not Q^T)
+        if (is_seed && !seed_move_possible(lone, pairP, xhi, tmask)) continue;
+        mvs |= bit;
+      }
+      auto fetch = [&](int b, T (&nv)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nv[j] = (p + base + (xhi ^ (1u << b)))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
+      };
+      auto take = [&](int b, const T (&nv)[NJ]) {
+        const bool is_seed = joint && b == seedb;
+        const T Lb = Ltab[b * 64 + lane] * hx[b];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = wave * NJ + j;
+          const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+          const bool on = !is_seed || (((xhi | xl) & lone) == 0 && ((((xhi | xl) & pairP) << 1) == ((xhi | xl) & (pairP << 1))));
+          acc[j] += on ? Lb * Urow[b * 64 + r] * nv[j] : T(0);
+        }
+      };
+      T n0[NJ], n1[NJ];
+      int b0 = -1, b1 = -1;
+      if (mvs) { b0 = __ffs(mvs) - 1; mvs &= mvs - 1; fetch(b0, n0); }
+#if MMHN_KV_PRE >= 2
+      if (mvs) { b1 = __ffs(mvs) - 1; mvs &= mvs - 1; fetch(b1, n1); }
+#endif
+      // lane bits: neighbour = other lane of the same row (conflict-free ds_read_b64 from the staged tile)
+#pragma unroll 1
+      for (int b = 0; b < 6; ++b) {
+        const T Lb = Ltab[b * 64 + lane] * hx[b];
+        const bool has = (lane >> b) & 1;
+        const bool on = TR ? !has : has;
+        const uint32_t nl = (uint32_t)lane ^ (1u << b);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = wave * NJ + j;
+          const T nb = tile[((uint32_t)r << 6) | nl];
+          acc[j] += on ? Lb * Urow[b * 64 + r] * nb : T(0);
+        }
+      }
+      // row bits: neighbour = same lane of another row of the tile
+#pragma unroll 1
+      for (int b = 6; b < t; ++b) {
+        const T Lb = Ltab[b * 64 + lane] * hx[b];
+        const int rb = 1 << (b - 6);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = wave * NJ + j;
+          const bool has = (r & rb) != 0;
+          if (TR ? !has : has) acc[j] += Lb * Urow[b * 64 + r] * tile[((r ^ rb) << 6) | lane];
+        }
+      }
+      if (b0 >= 0) take(b0, n0);
+      if (b1 >= 0) take(b1, n1);
+      while (mvs) {
+        b0 = __ffs(mvs) - 1; mvs &= mvs - 1;
+        b1 = mvs ? __ffs(mvs) - 1 : -1;
+        if (b1 >= 0) mvs &= mvs - 1;
+        fetch(b0, n0);
+        if (b1 >= 0) fetch(b1, n1);
+        take(b0, n0);
+        if (b1 >= 0) take(b1, n1);
+      }
+    } else {
+      // generic path (seeding bit inside the tile, or a seed = 0 tile with PT == MT states): per-state conditions
+      const Desc& d = dsh;
+#pragma unroll 1
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave * NJ + j;
+        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+        const uint32_t x = xhi | xl;
+        const bool ss = seed_set(d, x);
+        const bool e0x = eq_noseed(d, x);
+        T a = 0;
+        for (int b = 0; b < k; ++b) {
+          const uint32_t bit = 1u << b;
+          const bool has = (x >> b) & 1u;
+          const int c = d.cls[b];
+          uint32_t nb = x ^ bit;
+          bool cond;
+          if (joint && c == CS) cond = (TR ? !has : has) && e0x;
+          else if (ss) cond = TR ? !has : has;
+          else if ((d.pairP >> b) & 1u) {
+            const uint32_t both = 3u << b;
+            nb = x ^ both;
+            cond = e0x && (TR ? (x & both) == 0 : (x & both) == both);
+          } else cond = false;
+          if (cond) {
+            const T nv = ((nb >> t) == H) ? tile[nb & tmask] : p[base + nb];
+            a += Ltab[b * 64 + lane] * hx[b] * Urow[b * 64 + r] * nv;
+          }
+        }
+        acc[j] = a;
+      }
+    }
+    // y is not read again by this launch: it leaves through LDS as 16-byte write-through stores that do not stay in
+    // the XCD's L2, which keeps the p tiles that later tiles read as neighbours
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tile[((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane] = acc[j];
+    __syncthreads();
+    for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
+      const f32x4 val = *reinterpret_cast<const f32x4*>(&tile[e]);
+      T* dst = y + base + xhi + e;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+    }
+    if (it + 1 < tpw) __syncthreads();                       // the tile (and hx) are rewritten by the next trip
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // k_tsolve: one tile of the triangular solve  (D - Q) y = rhs   (TR: transposed system).
 //
 // (D - Q) is lower triangular in index order: every transition sets bits, so y[x] only needs
