@@ -292,9 +292,9 @@ def main():
             return o
 
         T = "double" if a.dtype == "f64" else "float"
-        rf_fwd = kern("psolve_fwd", f"k_psolve<{T},false,*> (forward substitution solve, one workgroup per patient)",
+        rf_fwd = kern("psolve_fwd", f"k_psolve2<{T},false> (forward substitution solve, one workgroup per patient)",
                       "solution written once: live (seeded) tiles x 2^12 x sizeof(dtype)")
-        rf_adj = kern("psolve_adj", f"k_psolve<{T},true,*> (adjoint substitution solve)", "solution written once")
+        rf_adj = kern("psolve_adj", f"k_psolve2<{T},true> (adjoint substitution solve)", "solution written once")
         rf_marg = kern("pclass", f"k_pclass<{T}> (class marginals of pi (x) q)", "pi and q_J read once (live tiles)")
         rf_other = kern("other_solve", "k_tsolve / k_sweep (level-by-level solves of the marginal single-tumour problems)",
                         "per tile: solution written once (+ dense rhs / lidg vector reads)")
