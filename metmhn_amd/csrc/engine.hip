@@ -97,9 +97,12 @@ struct Batch {
   std::vector<int2> mapX;
   DevArr<int2> d_mapX;
   DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
+  DevArr<int2> d_grcJ;           // the three joint kinds in one list (kind in bits 24+ of .y): one launch
   // small-space path (small.h): patients by size class of their largest single-tumour space; sp_ok: every one fits a tile
-  std::vector<int> sp_list[SP_NCLASS];
-  DevArr<int> d_sp_list[SP_NCLASS];
+  // [0]: patients that are their own single-tumour problem (dat types 0-2: nothing of the joint path feeds them),
+  // [1]: paired patients (their single-tumour problems are marginals of the joint forward solution)
+  std::vector<int> sp_list[2][SP_NCLASS];
+  DevArr<int> d_sp_list[2][SP_NCLASS];
   bool sp_ok = false;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   std::vector<int> ptoff;
@@ -264,6 +267,10 @@ struct Engine : EngineBase {
   size_t ws_limit = 0;
   DevArr<Params<T>> d_par;
   Params<T>* h_par = nullptr;         // pinned: the per-evaluation upload is a true async copy
+  double* h_abi = nullptr;            // pinned landing buffer of the result download
+  // HIP events around the dominant kernels (mmhn_get_counters): an event record costs ~5 us of host time, which a short
+  // evaluation cannot afford (it is bound by the host's issue rate) - only batches of at least 2^24 states are timed
+  bool time_kernels = true;
   // cohort
   std::vector<int8_t> dat;
   long long n_pat = 0;
@@ -271,7 +278,13 @@ struct Engine : EngineBase {
   std::vector<Batch> batches;
   double n_em = 0;
   // workspace (sized for the largest batch)
-  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, Abuf, GS, GJ, DJ, dots, bmJ, bmS, tabJ, tabS;
+  DevArr<T> pi, lidgJ, qJ, rhsJ, rhsS, pS, lidgS, qS, seedS, GS, dots, bmJ, bmS, tabJ, tabS;
+  // accumulators of the joint gradient that must be zero on entry - rows of the three G matrices, observation-rate rows,
+  // class marginals - share one allocation, laid out per batch and cleared by ONE memset at the start of the batch
+  DevArr<T> zarena;
+  struct View { T* p = nullptr; } GJ, DJ, Abuf;
+  static long long zarena_elems(long long nJ, long long asize, int N) { return up4(3 * nJ * N * N) + up4(3 * nJ * N) + up4(asize); }
+  static long long up4(long long v) { return (v + 3) / 4 * 4; }
   int pi_owner = -1, qJ_owner = -1;   // batch whose (pruned) layout the zero-initialised buffers hold
   DevArr<double> lp, out, sums, abi_sums;
   DevArr<JLink<T>> links;
@@ -283,8 +296,8 @@ struct Engine : EngineBase {
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
-  hipStream_t side[SP_NCLASS - 1] = {};   // side streams of the small-space path (size classes run side by side)
-  hipEvent_t ev_fork = nullptr, ev_join[SP_NCLASS - 1] = {};
+  hipStream_t side[2] = {};               // side streams of the small-space path
+  hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
   int kv_version = 2;           // MMHN_KV=1: the round-1 kronvec kernel (k_sweep) also for plain products on multi-tile spaces
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
@@ -337,14 +350,13 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 64, SP_PPB0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    for (int i = 0; i < SP_NCLASS - 1; ++i) {
+    for (int i = 0; i < 2; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+      HIPCHECK(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
-    HIPCHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -368,12 +380,13 @@ struct Engine : EngineBase {
   ~Engine() override {                       // runs under the DevGuard of mmhn_destroy
     comm_destroy();
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (int i = 0; i < SP_NCLASS - 1; ++i) {
+    for (int i = 0; i < 2; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+      if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
       if (side[i]) (void)hipStreamDestroy(side[i]);
     }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (h_par) (void)hipHostFree(h_par);
+    if (h_abi) (void)hipHostFree(h_abi);
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -416,7 +429,7 @@ struct Engine : EngineBase {
                     const T* lidg, const T* rhs, int rhs_mode, const T* scal, double alg_bytes, const T* tab) {
     if (ntiles == 0) return;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = alg_bytes > 0;
+    const bool timed = alg_bytes > 0 && time_kernels;
     if (timed) {
       if (ev_used == ev_pool.size()) {
         hipEvent_t a, b;
@@ -484,14 +497,15 @@ struct Engine : EngineBase {
     return out;
   }
   // partial rows of the subset chunks are added up: G (and dj) must be zero on entry
+  // kind < 0: the work list holds the three joint kinds (kind in bits 24+ of the chunk field), G matrices gstride apart
   void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind,
-                        const DevArr<int2>& chunks, T* dj = nullptr) {
+                        const DevArr<int2>& chunks, T* dj = nullptr, long long gstride = 0) {
     if (nprob == 0 || chunks.n == 0) return;
     const int maxhi = std::max(0, std::min(maxk, GR_CHUNK) - 6);     // high-bit accumulators: bits inside a chunk only
     const size_t lds = ((size_t)WAVES * 192 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
     hipLaunchKernelGGL((k_grad_rows<T>), dim3((unsigned)chunks.n, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream,
-                       descs, d_par.p, A, p, q, G, kind, maxhi, dj, chunks.p, nprob);
+                       descs, d_par.p, A, p, q, G, kind, maxhi, dj, chunks.p, nprob, gstride);
     HIPCHECK(hipGetLastError());
   }
   void zero(T* p, long long count) {
@@ -500,6 +514,11 @@ struct Engine : EngineBase {
   // timed launch helper shared by the two solvers
   template <typename F>
   void timed(int slot, double alg_bytes, F&& launch) {
+    if (!time_kernels) {
+      launch();
+      HIPCHECK(hipGetLastError());
+      return;
+    }
     if (ev_used == ev_pool.size()) {
       hipEvent_t a, b;
       HIPCHECK(hipEventCreate(&a));
@@ -542,7 +561,11 @@ struct Engine : EngineBase {
     if (b.all_multi && psolve_version == 2) {
       const long long spare = (80 * 1024 - 64) - (long long)psolve2_lds(mk);
       const int dl_cap = (int)std::max<long long>(0, std::min<long long>(PS_DL2, spare / (long long)sizeof(T)));
+#ifdef MMHN_ABL_PACK
+      const size_t lds = std::max<size_t>(psolve2_lds(mk) + (size_t)dl_cap * sizeof(T), 100 * 1024);   // one workgroup per CU
+#else
       const size_t lds = psolve2_lds(mk) + (size_t)dl_cap * sizeof(T);
+#endif
       const double bytes = (double)b.ptiles.size() * (double)(1 << TB) * sizeof(T);
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
         if (tr) hipLaunchKernelGGL((k_psolve2<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
@@ -729,7 +752,8 @@ struct Engine : EngineBase {
     }
     flush();
     // upload the static descriptions and size the workspace
-    long long mvJ = 0, mvS = 0, mA = 0, mtJ = 0, mtS = 0;
+    long long mvJ = 0, mvS = 0, mtJ = 0, mtS = 0;
+    size_t mZ = 0;
     int bid = 0;
     size_t mnJ = 0, mnS = 0, mp = 0;
     for (auto& b : batches) {
@@ -771,7 +795,7 @@ struct Engine : EngineBase {
       }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
       b.sp_ok = !b.dS.empty();
-      for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[c].clear();
+      for (int w = 0; w < 2; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) {
         const PatRec& pr = b.pats[pi_];
         int ks = -1;
@@ -780,7 +804,7 @@ struct Engine : EngineBase {
         if (ks > TB) { b.sp_ok = false; break; }
         int c = 0;
         while (ks > spatient_class_maxk(c)) ++c;
-        b.sp_list[c].push_back((int)pi_);
+        b.sp_list[pr.j >= 0 ? 1 : 0][c].push_back((int)pi_);
       }
       {
         // largest spaces first: the waves of one workgroup (class 0: one patient each) then finish together and the
@@ -791,22 +815,30 @@ struct Engine : EngineBase {
           for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) ks = std::max(ks, 64 * b.dS[pr.s[part]].k + (pr.s[0] >= 0 && pr.s[1] >= 0 ? 32 : 0) + pr.kind);
           return ks;
         };
-        for (int c = 0; c < SP_NCLASS; ++c)
-          std::stable_sort(b.sp_list[c].begin(), b.sp_list[c].end(), [&](int x, int y) { return ksize(x) > ksize(y); });
+        for (int w = 0; w < 2; ++w)
+          for (int c = 0; c < SP_NCLASS; ++c)
+            std::stable_sort(b.sp_list[w][c].begin(), b.sp_list[w][c].end(), [&](int x, int y) { return ksize(x) > ksize(y); });
       }
-      for (int c = 0; c < SP_NCLASS; ++c) {
-        const size_t need_c = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (c <= 1 ? SP_PPB0 : 1);
-        if (!b.sp_list[c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
-        up(b.d_sp_list[c], b.sp_list[c]);
-      }
+      for (int w = 0; w < 2; ++w)
+        for (int c = 0; c < SP_NCLASS; ++c) {
+          const size_t need_c = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (c == 0 ? SP_PPB0 : 1);
+          if (!b.sp_list[w][c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
+          up(b.d_sp_list[w][c], b.sp_list[w][c]);
+        }
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles); up(b.d_mapX, b.mapX);
-      for (int kd = 0; kd < 4; ++kd) {
-        std::vector<int2> gc = grad_chunks(kd == GK_S ? b.dS : b.dJ, kd);
-        up(b.d_grc[kd], gc);
+      {
+        std::vector<int2> all;
+        for (int kd = 0; kd < 4; ++kd) {
+          std::vector<int2> gc = grad_chunks(kd == GK_S ? b.dS : b.dJ, kd);
+          up(b.d_grc[kd], gc);
+          if (kd != GK_S) for (int2 e : gc) all.push_back(int2{e.x, e.y | (kd << 24)});
+        }
+        up(b.d_grcJ, all);
       }
-      mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS); mA = std::max(mA, b.asize);
+      mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS);
+      mZ = std::max<size_t>(mZ, (size_t)zarena_elems((long long)b.dJ.size(), b.asize, N));
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
@@ -816,8 +848,8 @@ struct Engine : EngineBase {
     tabJ.alloc(mtJ); tabS.alloc(mtS);
     pi_owner = qJ_owner = -1;
     rhsS.alloc(mvS); pS.alloc(mvS); lidgS.alloc(mvS); qS.alloc(mvS);
-    seedS.alloc(mnS); Abuf.alloc(mA);
-    GS.alloc(mnS * N * N); GJ.alloc(3 * mnJ * N * N); DJ.alloc(3 * mnJ * N);
+    seedS.alloc(mnS);
+    GS.alloc(mnS * N * N); zarena.alloc(mZ);
     dots.alloc(2 * mp); bmJ.alloc(mnJ * 64); bmS.alloc(mnS * 64);
     lp.alloc(mp); out.alloc(mp * stride());
   }
@@ -832,6 +864,44 @@ struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- one evaluation
   // host_out (optional): per-patient rows [n_pat][stride]; sums: [2][stride] (EM, NM)
+  // small-space path (small.h): every single-tumour space of the batch fits one tile -> one launch per size class does
+  // stage 4, the adjoint seeds, the single-tumour gradients and the <q, rhs> dots, one workgroup (or wave) per patient.
+  // which = 0: the patients that are their own problem (launched first: nothing of the joint path feeds them), 1: the
+  // paired ones (after k_gather_marg).  The size classes are independent of each other.
+  // Streams: the own-problem launches go to side[0], next to the joint path on the main stream, and are joined before the
+  // assembly; of the paired launches the 1024-thread class goes to side[1], the merged one stays on the main stream.
+  bool small_forked[2] = {false, false};
+  void small_classes(const Batch& b, int which, bool grad) {
+    const int n0 = (int)b.sp_list[which][0].size(), n1 = (int)b.sp_list[which][1].size(), n2 = (int)b.sp_list[which][2].size();
+    const int mk0 = spatient_class_maxk(0), mk1 = spatient_class_maxk(1), mk2 = spatient_class_maxk(2);
+    const bool on_side = which == 0 ? (n0 + n1 + n2 > 0) : n2 > 0;
+    hipStream_t sd = side[which];
+    if (on_side) {
+      HIPCHECK(hipEventRecord(ev_fork[which], stream));
+      HIPCHECK(hipStreamWaitEvent(sd, ev_fork[which], 0));
+    }
+#define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, rhsS.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
+    if (n2) {
+      const size_t lds = (spatient_lds<T>(N, mk2) + 15) / 16 * 16;
+      hipLaunchKernelGGL((k_spatient<T, 1024, 1>), dim3(n2), dim3(1024), lds, sd, b.d_sp_list[which][2].p, n2, SP_TAIL, mk2, N, grad ? 1 : 0);
+      HIPCHECK(hipGetLastError());
+    }
+    if (n0 + n1) {
+      const size_t lds = std::max((spatient_lds<T>(N, mk0) + 15) / 16 * 16 * SP_PPB0, n1 ? (spatient_lds<T>(N, mk1) + 15) / 16 * 16 : 0);
+      hipLaunchKernelGGL((k_spatient2<T>), dim3((n0 + SP_PPB0 - 1) / SP_PPB0 + n1), dim3(256), lds, which == 0 ? sd : stream,
+                         b.d_sp_list[which][0].p, n0, mk0, b.d_sp_list[which][1].p, n1, mk1, SP_TAIL, N, grad ? 1 : 0);
+      HIPCHECK(hipGetLastError());
+    }
+#undef SP_TAIL
+    if (on_side) HIPCHECK(hipEventRecord(ev_join[which], sd));
+    small_forked[which] = on_side;
+    if (which == 1) small_join(1);
+  }
+  void small_join(int which) {
+    if (small_forked[which]) HIPCHECK(hipStreamWaitEvent(stream, ev_join[which], 0));
+    small_forked[which] = false;
+  }
+
   void evaluate(const double* lt, const double* ldp, const double* ldm, bool grad, double* host_sums,
                 double* host_out) {
     auto t0 = std::chrono::steady_clock::now();
@@ -844,6 +914,15 @@ struct Engine : EngineBase {
       const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};
       const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS, tabS.p};
       const bool fused_small = small_path && !use_jacobi && nS > 0 && b.sp_ok;
+      time_kernels = b.vecJ + b.vecS >= (1ll << 24);
+      const long long gjs = (long long)nJ * N * N;
+      GJ.p = zarena.p;
+      DJ.p = GJ.p + up4(3 * gjs);
+      Abuf.p = DJ.p + up4(3ll * nJ * N);
+      if (grad && nJ) zero(zarena.p, zarena_elems(nJ, b.asize, N));
+      // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
+      // start now on the side streams, next to the joint forward solve; the assembly waits for them
+      if (fused_small) small_classes(b, 0, grad);
       prep(b.d_dJ.p, nJ, tabJ.p);
       if (!fused_small) prep(b.d_dS.p, nS, tabS.p);        // (k_spatient builds its own tables in LDS)
       const bool per_patient = !use_jacobi && nJ >= psolve_min;
@@ -867,8 +946,6 @@ struct Engine : EngineBase {
       if (per_patient) psolve(false, b, pi.p, 2);
       else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
       // 3 marginal right-hand sides
-      // small-space path (small.h): every single-tumour space of the batch fits one tile -> one launch does stage 4,
-      // the adjoint seeds, the single-tumour gradients and the <q, rhs> dots, one workgroup per patient
       if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ) {
         hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
@@ -876,33 +953,7 @@ struct Engine : EngineBase {
         HIPCHECK(hipGetLastError());
       }
       if (fused_small) {
-        // the size classes are independent.  Measured on the LUAD-reduced cohort (three kernels run side by side, a
-        // fourth stream waits): classes 1 (k 5-6) and 3 (k 10-12) go to side streams, classes 0 (k <= 4) and 2 (k 7-9)
-        // follow each other on the main stream - about equal spans
-        int forked = 0;
-        const int order[SP_NCLASS] = {3, 1, 0, 2};
-        for (int oi = 0; oi < SP_NCLASS; ++oi) {
-          const int c = order[oi];
-          const int cnt_c = (int)b.sp_list[c].size(), mk = spatient_class_maxk(c);
-          if (cnt_c == 0) continue;
-          hipStream_t st = stream;
-          if (c == 1 || c == 3) {
-            if (!forked) HIPCHECK(hipEventRecord(ev_fork, stream));
-            st = side[c - 1];
-            HIPCHECK(hipStreamWaitEvent(st, ev_fork, 0));
-            forked |= 1 << c;
-          }
-          const size_t slice = (spatient_lds<T>(N, mk) + 15) / 16 * 16;
-#define SP_ARGS(threads, ppb) dim3((cnt_c + (ppb) - 1) / (ppb)), dim3((threads) * (ppb)), slice * (ppb), st, b.d_sp_list[c].p, cnt_c, b.d_pats.p, \
-                b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, rhsS.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p, mk, N, grad ? 1 : 0
-          if (c <= 1) hipLaunchKernelGGL((k_spatient<T, 64, SP_PPB0>), SP_ARGS(64, SP_PPB0));
-          else if (c == 2) hipLaunchKernelGGL((k_spatient<T, 256, 1>), SP_ARGS(256, 1));
-          else hipLaunchKernelGGL((k_spatient<T, 1024, 1>), SP_ARGS(1024, 1));
-#undef SP_ARGS
-          HIPCHECK(hipGetLastError());
-          if (st != stream) HIPCHECK(hipEventRecord(ev_join[c - 1], st));
-        }
-        for (int c = 1; c < SP_NCLASS; ++c) if (forked & (1 << c)) HIPCHECK(hipStreamWaitEvent(stream, ev_join[c - 1], 0));
+        small_classes(b, 1, grad);
       } else {
         fill_e0(b);
         // 4 single-tumour spaces
@@ -938,8 +989,7 @@ struct Engine : EngineBase {
           if (use_jacobi) solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
           else if (per_patient) psolve(true, b, qJ.p, 3);
           else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
-          // 6 joint gradient
-          zero(Abuf.p, b.asize);
+          // 6 joint gradient (accumulators cleared at the start of the batch)
           if (per_patient) {
             // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
             const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
@@ -957,14 +1007,11 @@ struct Engine : EngineBase {
           HIPCHECK(hipGetLastError());
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
-          const long long gjs = (long long)nJ * N * N;
-          zero(GJ.p, 3 * gjs);
-          zero(DJ.p, 3ll * nJ * N);
-          for (int kd = 0; kd < 3; ++kd)
-            launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p + kd * gjs, kd, b.d_grc[kd], DJ.p);
+          launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p, -1, b.d_grcJ, DJ.p, gjs);
         }
         // 7 assembly
       }
+      if (fused_small) small_join(0);
       hipLaunchKernelGGL((k_finalize<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p, b.d_dS.p,
                          d_par.p, GS.p, GJ.p, (long long)nJ * N * N, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, out.p, N,
                          grad ? 1 : 0);
@@ -980,6 +1027,7 @@ struct Engine : EngineBase {
           std::memcpy(host_out + (size_t)b.pats[i].row * st, tmp.data() + (size_t)i * st, st * sizeof(double));
       }
     }
+    time_kernels = true;
     if (host_sums) {
       std::vector<double> hs(2 * st);
       HIPCHECK(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -997,16 +1045,26 @@ struct Engine : EngineBase {
   // sums layout of the C ABI (include/metmhn_amd.h): packed on the device, summed over the ranks of the
   // communicator (one RCCL all-reduce on this stream, regularized_optimization.py:256-266 needs nothing else),
   // then one download and one synchronisation per evaluation
+  // (A hipGraph replay of the evaluation was measured on the LUAD-reduced cohort, ROCm 7.0.2: the host is free after
+  // 75 us instead of 535 us, but the graph takes 660 us to execute against 550 us for the eager launches - dropped.)
   void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
     auto t0 = std::chrono::steady_clock::now();
     const int total = 4 + 2 * N * N + 3 * N;
     abi_sums.alloc(total);
+    if (!h_abi) HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)total * sizeof(double), hipHostMallocDefault));
     evaluate(lt, ldp, ldm, grad, nullptr, nullptr);
     hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, abi_sums.p);
     HIPCHECK(hipGetLastError());
     if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
-    HIPCHECK(hipMemcpyAsync(o, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    const auto t_issued = std::chrono::steady_clock::now();
     HIPCHECK(hipStreamSynchronize(stream));
+    std::memcpy(o, h_abi, total * sizeof(double));
+    static const bool trace_host = std::getenv("MMHN_TRACE_HOST") != nullptr;   // diagnostic: host time to issue vs total
+    if (trace_host)
+      std::fprintf(stderr, "[mmhn] evaluation issued after %.1f us, complete after %.1f us%s\n",
+                   std::chrono::duration<double, std::micro>(t_issued - t0).count(),
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), "");
     finish_eval(t0);
   }
 

@@ -1403,8 +1403,13 @@ __device__ __forceinline__ T cluster_bcast(T v, int src) {
 // 27 %, LDS 39 % busy with 52 % of its cycles conflicts), not by HBM.
 // Same arithmetic as k_psolve term by term (rate_b(s) = Ltab[b][s & 63] * Utab[b][s >> 6], s the source state).
 // ------------------------------------------------------------------------------------
+#ifdef MMHN_ABL_PACK   // timing-only ablation (wrong results): the work of MMHN_ABL_PACK tiles per phase, one workgroup per CU
+#define PS2_WPE 4
+#else
+#define PS2_WPE TSB_WPE
+#endif
 template <typename T, bool TR>
-__global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve2(const Desc* __restrict__ descs,
+__global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict__ descs,
                                                     const int* __restrict__ pt_off,
                                                     const uint32_t* __restrict__ ptiles,
                                                     const Params<T>* __restrict__ par, T* y, int rhs_mode,
@@ -1547,6 +1552,9 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve2(const Desc* __restrict
     if (tid + TSB < ndl) dl[tid + TSB] = dval2;
     const uint32_t hP = pxt[384], hM = pxt[385];
     // ---- right-hand side (natural states).  Forward: e_0 lies in the seed = 0 part, so zero here.
+#ifdef MMHN_ABL_PACK
+    for (int rep = 0; rep < MMHN_ABL_PACK; ++rep) {
+#endif
     T acc[NJ];
 #pragma unroll
     for (int jq = 0; jq < NJ; ++jq) acc[jq] = T(0);
@@ -1643,6 +1651,9 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve2(const Desc* __restrict
     }
     STAMP(2);
     __syncthreads();
+#ifdef MMHN_ABL_PACK
+    }
+#endif
     STAMP(3);
     // ---- step B: levels over the popcount of the base state.  HP lanes of one DPP quad share a group (HP = 1, 2, 4;
     // a level has at most C(BB, BB/2) groups, a quarter of the workgroup): each lane takes every HP-th base-bit move,
@@ -1657,8 +1668,15 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve2(const Desc* __restrict
       for (int s = 0; s <= BB; ++s) {
         const int level = TR ? BB - s : s;
         const uint32_t goff = BP.v[level], gcnt = BP.v[level + 1] - goff;
+#ifdef MMHN_ABL_PACK
+        for (uint32_t item = gi; item < gcnt * MMHN_ABL_PACK; item += (uint32_t)(TSB >> LHP)) {
+          uint32_t gsel = item;
+          while (gsel >= gcnt) gsel -= gcnt;
+          const uint32_t ub = pml[goff + gsel];
+#else
         if (gi < gcnt) {
           const uint32_t ub = pml[goff + gi];
+#endif
           const uint32_t ulo = (ub & LOM) << GL, uhi = ub >> (6 - GL);
           // this lane's share of the group's right-hand side
           T z[NJ];
@@ -1773,9 +1791,15 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve2(const Desc* __restrict
 #else
     const uint32_t xst = xhi;
 #endif
+#ifdef MMHN_ABL_PACK
+    for (int rep = 0; rep < MMHN_ABL_PACK; ++rep)
+#endif
     {
       const group_t gq = *reinterpret_cast<const group_t*>(yt + ((uint32_t)tid << G));
       T* yo = y + base + xst + ((uint32_t)tid << GL);
+#ifdef MMHN_ABL_PACK
+      asm volatile("" ::: "memory");
+#endif
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {
         lvec_t ov;
@@ -2460,15 +2484,19 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      const Params<T>* __restrict__ par,
                                                      const T* __restrict__ A,
                                                      const T* __restrict__ p,
-                                                     const T* __restrict__ q, T* G, int kind,
+                                                     const T* __restrict__ q, T* G, int kind_arg,
                                                      int maxhi, T* DJ, const int2* __restrict__ chunks,
-                                                     int nprob) {
+                                                     int nprob, long long gstride) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][3][64]: rate products over subset bits 0-5, 6-11, 12-17
   T* rowbuf = Tlo + WAVES * 192;                // [WAVES][32]
   T* hiacc = rowbuf + WAVES * 32;               // [WAVES][maxhi][64]
   __shared__ int lev[32];                       // event of local bit l
-  const int prob = chunks[blockIdx.x].x, chunk = chunks[blockIdx.x].y;   // (problem, subset chunk) work list
+  // (problem, subset chunk) work list; kind_arg < 0: the kind rides in bits 24+ of the chunk field and selects the G matrix
+  const int prob = chunks[blockIdx.x].x;
+  const int kind = kind_arg < 0 ? chunks[blockIdx.x].y >> 24 : kind_arg;
+  const int chunk = chunks[blockIdx.x].y & 0xffffff;
+  if (kind_arg < 0) G += (long long)kind * gstride;
   const Desc& d = descs[prob];
   const int N = d.N, n = N - 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;

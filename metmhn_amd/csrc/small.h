@@ -45,9 +45,9 @@ __device__ __forceinline__ T wave_sum_dpp(T v) {
   return lane63(v);
 }
 
-constexpr int SP_NCLASS = 4;
-constexpr int SP_PPB0 = 4;                    // patients (waves) per workgroup of the two one-wave classes
-__host__ __device__ inline int spatient_class_maxk(int c) { return c == 0 ? 4 : c == 1 ? 6 : c == 2 ? 9 : TB; }
+constexpr int SP_NCLASS = 3;
+constexpr int SP_PPB0 = 4;                    // patients (waves) per workgroup of the one-wave class
+__host__ __device__ inline int spatient_class_maxk(int c) { return c == 0 ? 6 : c == 1 ? 9 : TB; }
 __host__ __device__ inline int spatient_lstride(int maxk) { return maxk < 6 ? 1 << maxk : 64; }
 __host__ __device__ inline int spatient_rows(int maxk) { return maxk > 6 ? 1 << (maxk - 6) : 1; }
 
@@ -63,12 +63,12 @@ __host__ __device__ inline size_t spatient_lds(int N, int maxk) {
 // SPB threads work on one patient; PPB patients share a workgroup (PPB > 1 only with SPB = 64: a wave per patient, no
 // workgroup barrier anywhere - thousands of one-wave workgroups are bound by the dispatcher, ~25 workgroups / us)
 template <typename T, int SPB, int PPB>
-__global__ __launch_bounds__(SPB * PPB) void k_spatient(const int* __restrict__ plist, int npl, const PatRec* __restrict__ pats, const Desc* __restrict__ dS,
-                                                  const Params<T>* __restrict__ par,
-                                                  const uint16_t* __restrict__ perm, const int* __restrict__ lvl,
-                                                  const T* __restrict__ rhsS, T* __restrict__ pS, T* __restrict__ qS,
-                                                  T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots,
-                                                  double* __restrict__ lp, int maxk, int N, int with_grad) {
+__device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int npl, const PatRec* __restrict__ pats, const Desc* __restrict__ dS,
+                                              const Params<T>* __restrict__ par,
+                                              const uint16_t* __restrict__ perm, const int* __restrict__ lvl,
+                                              const T* __restrict__ rhsS, T* __restrict__ pS, T* __restrict__ qS,
+                                              T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots,
+                                              double* __restrict__ lp, int maxk, int N, int with_grad, int block) {
   constexpr int SPW = SPB / 64;
   static_assert(PPB == 1 || SPB == 64, "several patients per workgroup: one wave each");
   extern __shared__ __align__(16) unsigned char smem_all[];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(SPB * PPB) void k_spatient(const int* __restrict__ 
   int* loff = lev + 64;                                    // offsets of the popcount levels in pml
   Desc& dsh = *reinterpret_cast<Desc*>(loff + TB + 2);     // the problem's descriptor (global reads off the critical loops)
   uint16_t* pml = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(&dsh) + DESC_PAD);   // states by popcount
-  const int pidx = (int)blockIdx.x * PPB + pslot;
+  const int pidx = block * PPB + pslot;
   if (pidx >= npl) return;
   const int pat = plist[pidx];
   const PatRec pr = pats[pat];
@@ -384,5 +384,29 @@ __global__ __launch_bounds__(SPB * PPB) void k_spatient(const int* __restrict__ 
   }
   STAMP_FLUSH(0);
 }
+
+#define SPATIENT_PARAMS const PatRec* __restrict__ pats, const Desc* __restrict__ dS, const Params<T>* __restrict__ par, \
+    const uint16_t* __restrict__ perm, const int* __restrict__ lvl, const T* __restrict__ rhsS, T* __restrict__ pS, \
+    T* __restrict__ qS, T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots, double* __restrict__ lp
+#define SPATIENT_ARGS pats, dS, par, perm, lvl, rhsS, pS, qS, GS, bmS, dots, lp
+
+// one size class per launch (the 1024-thread class)
+template <typename T, int SPB, int PPB>
+__global__ __launch_bounds__(SPB * PPB) void k_spatient(const int* __restrict__ plist, int npl, SPATIENT_PARAMS, int maxk, int N,
+                                                        int with_grad) {
+  spatient_body<T, SPB, PPB>(plist, npl, SPATIENT_ARGS, maxk, N, with_grad, (int)blockIdx.x);
+}
+
+// the two 256-thread classes in ONE launch - side by side without a second stream: workgroups [0, nb0) take SP_PPB0
+// one-wave patients each (list0, spaces of at most maxk0 bits), the others one patient each (list1, maxk1)
+template <typename T>
+__global__ __launch_bounds__(256) void k_spatient2(const int* __restrict__ list0, int n0, int maxk0, const int* __restrict__ list1,
+                                                   int n1, int maxk1, SPATIENT_PARAMS, int N, int with_grad) {
+  const int nb0 = (n0 + SP_PPB0 - 1) / SP_PPB0;
+  if ((int)blockIdx.x < nb0) spatient_body<T, 64, SP_PPB0>(list0, n0, SPATIENT_ARGS, maxk0, N, with_grad, (int)blockIdx.x);
+  else spatient_body<T, 256, 1>(list1, n1, SPATIENT_ARGS, maxk1, N, with_grad, (int)blockIdx.x - nb0);
+}
+#undef SPATIENT_PARAMS
+#undef SPATIENT_ARGS
 
 }  // namespace mmhn
