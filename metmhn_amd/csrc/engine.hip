@@ -13,7 +13,7 @@
 //   5  rhs_J = D_obs * scatter(q_S), q_J = (D - Q)^-T rhs_J  k_scatter_marg, k_sweep<true>
 //   6  joint gradient: class marginals, eq block, flow rows, observation-rate marginals
 //                                      k_class_marg, k_eq_flows, k_grad_rows, k_bit_marg
-//   7  per-patient assembly and deterministic cohort reduction  k_finalize, k_reduce
+//   7  per-patient assembly and deterministic cohort reduction  k_finalize, k_reduce_rows, k_reduce_parts
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>                 // types only: the library is opened at run time by mmhn_comm_init
 #include <dlfcn.h>
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void k_stream(double2* __restrict__ a, const d
   }
 }
 
-// sums[2][stride] (EM, NM rows of k_reduce) -> the buffer layout of mmhn_cohort_sums (include/metmhn_amd.h)
+// sums[2][stride] (EM, NM rows of k_reduce_parts) -> the buffer layout of mmhn_cohort_sums (include/metmhn_amd.h)
 __global__ void k_pack_sums(const double* __restrict__ sums, int N, double n_em, double n_pat, double* __restrict__ o) {
   const int st = 1 + N * N + 2 * N, NN = N * N;
   const double* em = sums;
@@ -286,7 +286,7 @@ struct Engine : EngineBase {
   static long long zarena_elems(long long nJ, long long asize, int N) { return up4(3 * nJ * N * N) + up4(3 * nJ * N) + up4(asize); }
   static long long up4(long long v) { return (v + 3) / 4 * 4; }
   int pi_owner = -1, qJ_owner = -1;   // batch whose (pruned) layout the zero-initialised buffers hold
-  DevArr<double> lp, out, sums, abi_sums;
+  DevArr<double> lp, out, sums, abi_sums, redbuf;
   DevArr<JLink<T>> links;
   // patient shards on several GPUs: one communicator per engine, the all-reduce runs on the engine's stream
   ncclComm_t comm = nullptr;
@@ -851,7 +851,7 @@ struct Engine : EngineBase {
     seedS.alloc(mnS);
     GS.alloc(mnS * N * N); zarena.alloc(mZ);
     dots.alloc(2 * mp); bmJ.alloc(mnJ * 64); bmS.alloc(mnS * 64);
-    lp.alloc(mp); out.alloc(mp * stride());
+    lp.alloc(mp); out.alloc(mp * stride()); redbuf.alloc(((mp + red_per((int)mp) - 1) / red_per((int)mp)) * 2 * (size_t)stride());
   }
 
   void fill_e0(const Batch& b) {
@@ -949,7 +949,7 @@ struct Engine : EngineBase {
       if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ) {
         hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
-                           b.d_dS.p, d_par.p, pi.p, rhsS.p);
+                           b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p);
         HIPCHECK(hipGetLastError());
       }
       if (fused_small) {
@@ -977,9 +977,6 @@ struct Engine : EngineBase {
         }
         if (nJ) {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
-          hipLaunchKernelGGL((k_links<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dJ.p,
-                             b.d_dS.p, d_par.p, links.p);
-          HIPCHECK(hipGetLastError());
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
           for (int part = 0; part < 2 && !fused_small; ++part) {
             hipLaunchKernelGGL((k_scatter_marg<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
@@ -1012,13 +1009,19 @@ struct Engine : EngineBase {
         // 7 assembly
       }
       if (fused_small) small_join(0);
-      hipLaunchKernelGGL((k_finalize<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p, b.d_dS.p,
-                         d_par.p, GS.p, GJ.p, (long long)nJ * N * N, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, out.p, N,
-                         grad ? 1 : 0);
+      const AsmArgs<T> aa{b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, GS.p, GJ.p, gjs, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, N,
+                          grad ? 1 : 0};
+      const int nelem = grad ? st : 1;
+      hipLaunchKernelGGL((k_finalize<T>), dim3(npat), dim3(BLOCK), 0, stream, aa, out.p);
       HIPCHECK(hipGetLastError());
-      hipLaunchKernelGGL(k_reduce, dim3(grad ? st : 1, 2), dim3(BLOCK), 0, stream, b.d_pats.p, npat, out.p, st,
-                         sums.p);
-      HIPCHECK(hipGetLastError());
+      {
+        const int per = red_per(npat), nchunk = (npat + per - 1) / per;
+        const dim3 cols((nelem + BLOCK - 1) / BLOCK);
+        hipLaunchKernelGGL(k_reduce_rows, dim3(cols.x, nchunk), dim3(BLOCK), 0, stream, b.d_pats.p, npat, per, out.p, st, nelem, redbuf.p);
+        HIPCHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_reduce_parts, dim3(cols.x, 2), dim3(BLOCK), 0, stream, redbuf.p, st, nelem, nchunk, sums.p);
+        HIPCHECK(hipGetLastError());
+      }
       if (host_out) {
         std::vector<double> tmp((size_t)npat * st);
         HIPCHECK(hipMemcpyAsync(tmp.data(), out.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));

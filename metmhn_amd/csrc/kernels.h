@@ -1969,18 +1969,24 @@ __device__ __forceinline__ T obs_const(const Desc& dj, const Params<T>& P, int p
   return c;
 }
 
-// rhsS[part problem] = [0 ; D * pi[compatible]]
+// rhsS[part problem] = [0 ; D * pi[compatible]];  links[joint problem]: where the right-hand side of the joint adjoint
+// comes from (rhs_mode 3 of k_psolve / k_tsolve) - the same constants, so they are written here
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict__ pats,
                                                        const Desc* __restrict__ dJ,
                                                        const Desc* __restrict__ dS,
                                                        const Params<T>* __restrict__ par,
-                                                       const T* __restrict__ pi, T* rhsS) {
+                                                       const T* __restrict__ pi, T* rhsS, JLink<T>* links) {
   __shared__ Desc djs;                                     // (the descriptor loops below must not be chains of global loads)
   const PatRec pr = pats[blockIdx.x];
   const int part = blockIdx.y;
   const int sp = part == 0 ? pr.s[0] : pr.s[1];
-  if (pr.j < 0 || sp < 0) return;
+  if (pr.j < 0) return;
+  const bool writes_link = threadIdx.x == 0 && blockIdx.z == 0;
+  if (sp < 0) {
+    if (writes_link) { links[pr.j].soff[part] = -1; links[pr.j].sk[part] = 0; links[pr.j].cst[part] = 0; }
+    return;
+  }
   load_desc(&djs, dJ + pr.j);
   const int ksS = dS[sp].k;
   const long long offS = dS[sp].off;
@@ -1990,6 +1996,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
   const uint32_t free_ = part == 0 ? dj.maskM : dj.maskP;
   const uint32_t half = 1u << (ksS - 1);
   const T c = obs_const(dj, par[PS_THETA], part);
+  if (writes_link) { links[pr.j].soff[part] = offS; links[pr.j].sk[part] = ksS; links[pr.j].cst[part] = c; }
   for (uint32_t e = blockIdx.z * BLOCK + threadIdx.x; e < half; e += gridDim.z * BLOCK) {
     const uint32_t x = pdep32(e, free_) | fixed;
     rhsS[offS + e] = 0;
@@ -2068,25 +2075,6 @@ __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* _
     l += log(dr);
   }
   lp[i] = l;
-}
-
-// per paired patient: where the right-hand side of the joint adjoint comes from (rhs_mode 3 of k_tsolve)
-template <typename T>
-__global__ void k_links(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dJ,
-                        const Desc* __restrict__ dS, const Params<T>* __restrict__ par, JLink<T>* links) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npat) return;
-  const PatRec pr = pats[i];
-  if (pr.j < 0) return;
-  JLink<T> L;
-  for (int part = 0; part < 2; ++part) {
-    if (pr.s[part] >= 0) {
-      L.soff[part] = dS[pr.s[part]].off;
-      L.sk[part] = dS[pr.s[part]].k;
-      L.cst[part] = obs_const(dJ[pr.j], par[PS_THETA], part);
-    } else { L.soff[part] = -1; L.sk[part] = 0; L.cst[part] = 0; }
-  }
-  links[pr.j] = L;
 }
 
 // ------------------------------------------------------------------------------------
@@ -2695,101 +2683,112 @@ __global__ __launch_bounds__(BLOCK) void k_bit_marg(const Desc* __restrict__ des
 // out[pat] = [ lp, G[N][N], d_dp[N], d_dm[N] ]
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_finalize(const PatRec* __restrict__ pats,
-                                                    const Desc* __restrict__ dJ,
-                                                    const Desc* __restrict__ dS,
-                                                    const Params<T>* __restrict__ par,
-                                                    const T* __restrict__ GS,
-                                                    const T* __restrict__ GJ, long long gj_stride,
-                                                    const T* __restrict__ dots,
-                                                    const T* __restrict__ DJ, long long dj_stride,
-                                                    const T* __restrict__ bmS,
-                                                    const double* __restrict__ lp, double* out,
-                                                    int N, int with_grad) {
-  const PatRec pr = pats[blockIdx.x];
-  const int n = N - 1;
-  const int stride = 1 + N * N + 2 * N;
-  double* o = out + (long long)blockIdx.x * stride;
-  const int tid = threadIdx.x;
-  const Params<T>& P0 = par[PS_THETA];
+struct AsmArgs {
+  const PatRec* pats; const Desc* dJ; const Desc* dS; const Params<T>* par;
+  const T* GS; const T* GJ; long long gj_stride; const T* dots; const T* DJ; long long dj_stride; const T* bmS;
+  const double* lp; int N; int with_grad;
+};
+
+// element e of patient `pat`'s row
+template <typename T>
+__device__ __forceinline__ double assemble_elem(const AsmArgs<T>& a, const PatRec& pr, int pat, int e) {
+  const int N = a.N, n = N - 1;
   if (pr.kind == 4) {                              // _grad_prim_obs_az, likelihood.py:464-478
+    const Params<T>& P0 = a.par[PS_THETA];
+    const int q = e - 1;
+    const bool diag = a.with_grad && q >= 0 && q < N * N && q / N == q % N;
+    if (e != 0 && !diag) return 0.0;
     double s = 0;
     for (int i = 0; i < N; ++i) s += (double)P0.th[i][i];
-    for (int e = tid; e < stride; e += BLOCK) o[e] = 0;
-    __syncthreads();
-    if (tid == 0) o[0] = -log1p(s);
-    if (with_grad && tid < N) o[1 + tid * N + tid] = -(double)P0.th[tid][tid] / (1.0 + s);
-    return;
+    return e == 0 ? -log1p(s) : -(double)P0.th[q / N][q / N] / (1.0 + s);
   }
-  if (tid == 0) o[0] = lp[blockIdx.x];
-  if (!with_grad) return;
-  // theta gradient
-  for (int e = tid; e < N * N; e += BLOCK) {
-    const int i = e / N, j = e % N;
+  if (e == 0) return a.lp[pat];
+  if (!a.with_grad) return 0.0;
+  if (e < 1 + N * N) {                             // theta gradient
+    const int q = e - 1, i = q / N, j = q % N;
     double g = 0;
     for (int part = 0; part < 2; ++part)
       if (pr.s[part] >= 0) {
-        const bool prim_space = dS[pr.s[part]].pset == PS_PRIM;
-        if (!(prim_space && j == n && i < n)) g += (double)GS[(long long)pr.s[part] * N * N + e];
+        const bool prim_space = a.dS[pr.s[part]].pset == PS_PRIM;
+        if (!(prim_space && j == n && i < n)) g += (double)a.GS[(long long)pr.s[part] * N * N + q];
       }
     if (pr.j >= 0)
-      for (int kd = 0; kd < 3; ++kd) g += (double)GJ[kd * gj_stride + (long long)pr.j * N * N + e];
-    o[1 + e] = g;
+      for (int kd = 0; kd < 3; ++kd) g += (double)a.GJ[kd * a.gj_stride + (long long)pr.j * N * N + q];
+    return g;
   }
   // observation-rate gradients
-  for (int i = tid; i < N; i += BLOCK) {
-    double gp = 0, gm = 0;
-    for (int part = 0; part < 2; ++part) {
-      if (pr.s[part] < 0) continue;
-      const Desc& ds = dS[pr.s[part]];
-      const T* g = GS + (long long)pr.s[part] * N * N;
-      double dd = 0;                               // d_diag[i] = -sum_{r != i} val[r, i], vanilla.py:392
-      for (int r = 0; r < N; ++r) if (r != i) dd -= (double)g[r * N + i];
-      if (pr.kind == 3) {
-        const Desc& dj = dJ[pr.j];
-        const double dot = (double)dots[2 * blockIdx.x + part];
-        if (part == 0) { gm += dd; if (i == n || dj.bitP[i] >= 0) gp += dot; }
-        else           { gp += dd; if (i == n || dj.bitM[i] >= 0) gm += dot; }
-      } else if (pr.kind == 2) {                   // _grad_met_obs, likelihood.py:481-512
-        const T* bm = bmS + (long long)pr.s[0] * 64;
-        const int b = ds.bitP[i];
-        if (b >= 0) {
-          if (b != ds.seedbit) gp -= (double)bm[b];
-          gm += 1.0 - (double)bm[32 + b];
-        }
-      } else {
-        gp += dd;                                  // _grad_prim_obs, likelihood.py:441-461
+  const int r0 = e - 1 - N * N, i = r0 % N;
+  double gp = 0, gm = 0;
+  for (int part = 0; part < 2; ++part) {
+    if (pr.s[part] < 0) continue;
+    const Desc& ds = a.dS[pr.s[part]];
+    const T* g = a.GS + (long long)pr.s[part] * N * N;
+    double dd = (double)g[i * N + i];              // d_diag[i] = -sum_{r != i} val[r, i], vanilla.py:392
+#pragma unroll 7
+    for (int r = 0; r < N; ++r) dd -= (double)g[r * N + i];
+    if (pr.kind == 3) {
+      const Desc& dj = a.dJ[pr.j];
+      const double dot = (double)a.dots[2 * pat + part];
+      if (part == 0) { gm += dd; if (i == n || dj.bitP[i] >= 0) gp += dot; }
+      else           { gp += dd; if (i == n || dj.bitM[i] >= 0) gm += dot; }
+    } else if (pr.kind == 2) {                     // _grad_met_obs, likelihood.py:481-512
+      const T* bm = a.bmS + (long long)pr.s[0] * 64;
+      const int b = ds.bitP[i];
+      if (b >= 0) {
+        if (b != ds.seedbit) gp -= (double)bm[b];
+        gm += 1.0 - (double)bm[32 + b];
       }
+    } else {
+      gp += dd;                                    // _grad_prim_obs, likelihood.py:441-461
     }
-    if (pr.kind == 3) {                            // minus x_partial_D_y(q_J, pi), likelihood.py:536,694-695
-      const long long o = (long long)pr.j * N + i;
-      gp -= (double)DJ[GK_P * dj_stride + o] + (double)DJ[GK_E * dj_stride + o];
-      gm -= (double)DJ[GK_M * dj_stride + o];
-    }
-    o[1 + N * N + i] = gp;
-    o[1 + N * N + N + i] = gm;
   }
+  if (pr.kind == 3) {                              // minus x_partial_D_y(q_J, pi), likelihood.py:536,694-695
+    const long long o = (long long)pr.j * N + i;
+    gp -= (double)a.DJ[GK_P * a.dj_stride + o] + (double)a.DJ[GK_E * a.dj_stride + o];
+    gm -= (double)a.DJ[GK_M * a.dj_stride + o];
+  }
+  return r0 < N ? gp : gm;
 }
 
-// sums[cls][e] = sum over patients of class cls (0: type != 0, 1: type 0) of out[pat][e]
-__global__ __launch_bounds__(BLOCK) void k_reduce(const PatRec* __restrict__ pats, int npat,
-                                                  const double* __restrict__ out, int stride,
-                                                  double* sums) {
-  __shared__ double red[BLOCK];
-  const int e = blockIdx.x, cls = blockIdx.y;
-  double acc = 0;
-  for (int i = threadIdx.x; i < npat; i += BLOCK) {
+// rows of all patients (mmhn_patient_grads)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_finalize(AsmArgs<T> a, double* out) {
+  const PatRec pr = a.pats[blockIdx.x];
+  const int stride = 1 + a.N * a.N + 2 * a.N;
+  double* o = out + (long long)blockIdx.x * stride;
+  for (int e = threadIdx.x; e < (a.with_grad ? stride : 1); e += BLOCK) o[e] = assemble_elem(a, pr, (int)blockIdx.x, e);
+}
+
+// cohort sums, stage 1: thread = element e (coalesced over the rows), workgroup (blockIdx.y) = a chunk of `per`
+// consecutive patients added in index order; part[chunk][cls][e], cls 0: type != 0 (EM), 1: type 0 (NM)
+constexpr int RED_MAX_CHUNKS = 128;
+__host__ __device__ inline int red_per(int npat) { return max(32, (npat + RED_MAX_CHUNKS - 1) / RED_MAX_CHUNKS); }
+__global__ __launch_bounds__(BLOCK) void k_reduce_rows(const PatRec* __restrict__ pats, int npat, int per,
+                                                       const double* __restrict__ out, int stride, int nelem,
+                                                       double* __restrict__ part) {
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= nelem) return;
+  const int i0 = blockIdx.y * per, i1 = min(npat, i0 + per);
+  double acc0 = 0, acc1 = 0;
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i) {
     const int kd = pats[i].kind;
-    const int c = (kd == 0 || kd == 4) ? 1 : 0;
-    if (c == cls) acc += out[(long long)i * stride + e];
+    const double v = out[(long long)i * stride + e];
+    if (kd == 0 || kd == 4) acc1 += v; else acc0 += v;
   }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = BLOCK / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) sums[cls * stride + e] += red[0];
+  part[((long long)blockIdx.y * 2 + 0) * stride + e] = acc0;
+  part[((long long)blockIdx.y * 2 + 1) * stride + e] = acc1;
+}
+
+// sums[cls][e] += the chunk sums in chunk order
+__global__ __launch_bounds__(BLOCK) void k_reduce_parts(const double* __restrict__ part, int stride, int nelem, int nchunk,
+                                                        double* sums) {
+  const int e = blockIdx.x * BLOCK + threadIdx.x, cls = blockIdx.y;
+  if (e >= nelem) return;
+  double acc = 0;
+#pragma unroll 8
+  for (int c = 0; c < nchunk; ++c) acc += part[((long long)c * 2 + cls) * stride + e];
+  sums[cls * stride + e] += acc;
 }
 
 }  // namespace mmhn
