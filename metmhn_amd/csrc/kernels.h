@@ -457,6 +457,8 @@ __global__ __launch_bounds__(KSB) void k_sweep(const Desc* __restrict__ descs,
 __device__ __forceinline__ int sgpr(int v);
 __device__ __forceinline__ uint32_t sgpr(uint32_t v);
 __device__ __forceinline__ long long sgpr64(long long v);
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 template <typename T>
 __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const int2* __restrict__ map,
@@ -472,7 +474,10 @@ __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const
 }
 
 #ifndef MMHN_KV_PRE
-#define MMHN_KV_PRE 1          // neighbour tiles k_kv fetches ahead of its LDS terms
+#define MMHN_KV_PRE 2          // neighbour tiles k_kv fetches ahead of its LDS terms
+#endif
+#ifndef MMHN_KV_DIRECT
+#define MMHN_KV_DIRECT 1         // y leaves as 8-byte write-through stores straight from the accumulators (0: through LDS as 16-byte stores)
 #endif
 #ifndef MMHN_KV_WPS
 #define MMHN_KV_WPS 4          // waves per SIMD k_kv's registers are sized for (4: two 512-thread workgroups per CU, 128 VGPRs)
@@ -552,7 +557,8 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
     // tables (once per problem), tile-bit factors and the tile: one barrier
     if (prob != cur_prob) {
       const T* src = tab + toff + k * k;
-      for (int e = tid; e < k * 64; e += KSB) { Ltab[e] = src[e]; Urow[e] = src[k * 64 + e]; }
+      for (int e = tid; e < k * 64; e += KSB) Ltab[e] = src[e];
+      if (kind == 2) for (int e = tid; e < k * 64; e += KSB) Urow[e] = src[k * 64 + e];    // (kind 0 reads U through the scalar unit)
       cur_prob = prob;
     }
     if (tid < k) hx[tid] = hxt[(long long)blk * maxk + tid];
@@ -569,7 +575,20 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0;
     if (kind == 0) {
-      // tile bits first: their neighbour rows come from other tiles (L2 / HBM) and fly while the LDS terms run
+      // Every term is  acc[j] += L_b[lane] * hx[b] * U_b[row] * neighbour.  The wave's NJ rows are consecutive and
+      // wave-uniform, so U_b[row] comes through the scalar unit from the table in global memory (one 64-byte scalar
+      // load per move instead of one LDS broadcast read per term), "is this move open" is a per-lane factor (lane
+      // bits), a compile-time pattern (row bits inside the wave's rows) or one scalar branch (higher row bits, tile
+      // bits): all loads of a move are issued before its first use and every term is one multiply and one FMA.
+      static_assert(NJ == 8, "k_kv: 8 consecutive rows per wave");
+      const int ws = sgpr(wave);
+      const T* __restrict__ Ug = tab + toff + k * k + k * 64 + ws * NJ;
+      auto urow = [&](int b, T (&u)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) u[j] = Ug[b * 64 + j];
+      };
+      // tile bits first: their neighbour rows come from other tiles (L2 / HBM) and fly while the LDS terms run.
+      // (Requesting them before the tile is staged, through the barrier, was measured slower: 102 VGPRs, 0.205 vs 0.197 ms.)
       uint32_t mvs = 0;
       for (int b = t; b < k; ++b) {
         const uint32_t bit = 1u << b;
@@ -581,17 +600,23 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
       }
       auto fetch = [&](int b, T (&nv)[NJ]) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) nv[j] = (p + base + (xhi ^ (1u << b)))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
+        for (int j = 0; j < NJ; ++j) nv[j] = (p + base + (xhi ^ (1u << b)))[(((uint32_t)(ws * NJ + j) << 6) | (uint32_t)lane)];
       };
       auto take = [&](int b, const T (&nv)[NJ]) {
         const bool is_seed = joint && b == seedb;
         const T Lb = Ltab[b * 64 + lane] * hx[b];
+        T u[NJ];
+        urow(b, u);
+        if (!is_seed) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int r = wave * NJ + j;
-          const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-          const bool on = !is_seed || (((xhi | xl) & lone) == 0 && ((((xhi | xl) & pairP) << 1) == ((xhi | xl) & (pairP << 1))));
-          acc[j] += on ? Lb * Urow[b * 64 + r] * nv[j] : T(0);
+          for (int j = 0; j < NJ; ++j) acc[j] = fma_t(Lb * u[j], nv[j], acc[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const uint32_t x = xhi | ((uint32_t)(ws * NJ + j) << 6) | (uint32_t)lane;
+            const bool on = (x & lone) == 0 && (((x & pairP) << 1) == (x & (pairP << 1)));
+            acc[j] += on ? Lb * u[j] * nv[j] : T(0);        // (a select: values of unwritten states may be anything)
+          }
         }
       };
       T n0[NJ], n1[NJ];
@@ -603,28 +628,44 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
       // lane bits: neighbour = other lane of the same row (conflict-free ds_read_b64 from the staged tile)
 #pragma unroll 1
       for (int b = 0; b < 6; ++b) {
-        const T Lb = Ltab[b * 64 + lane] * hx[b];
         const bool has = (lane >> b) & 1;
-        const bool on = TR ? !has : has;
-        const uint32_t nl = (uint32_t)lane ^ (1u << b);
+        const T Lb = (TR ? !has : has) ? Ltab[b * 64 + lane] * hx[b] : T(0);
+        const T* nrow = tile + ((uint32_t)(ws * NJ) << 6) + ((uint32_t)lane ^ (1u << b));
+        T u[NJ], nb[NJ];
+        urow(b, u);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int r = wave * NJ + j;
-          const T nb = tile[((uint32_t)r << 6) | nl];
-          acc[j] += on ? Lb * Urow[b * 64 + r] * nb : T(0);
-        }
+        for (int j = 0; j < NJ; ++j) nb[j] = nrow[j << 6];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = fma_t(Lb * u[j], nb[j], acc[j]);
       }
-      // row bits: neighbour = same lane of another row of the tile
-#pragma unroll 1
-      for (int b = 6; b < t; ++b) {
+      // row bits 6-8: the partner row is one of the wave's own rows, the pattern is known at compile time
+#pragma unroll
+      for (int b = 6; b < 9; ++b) {
         const T Lb = Ltab[b * 64 + lane] * hx[b];
         const int rb = 1 << (b - 6);
+        const T* rows = tile + ((uint32_t)(ws * NJ) << 6) + (uint32_t)lane;
+        T u[NJ];
+        urow(b, u);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int r = wave * NJ + j;
-          const bool has = (r & rb) != 0;
-          if (TR ? !has : has) acc[j] += Lb * Urow[b * 64 + r] * tile[((r ^ rb) << 6) | lane];
+          const bool has = (j & rb) != 0;
+          if (TR ? !has : has) acc[j] = fma_t(Lb * u[j], rows[(j ^ rb) << 6], acc[j]);
         }
+      }
+      // row bits 9-11: open or closed for the whole wave
+#pragma unroll 1
+      for (int b = 9; b < t; ++b) {
+        const int wb = 1 << (b - 9);
+        const bool has = (ws & wb) != 0;
+        if (TR ? has : !has) continue;
+        const T Lb = Ltab[b * 64 + lane] * hx[b];
+        const T* rows = tile + ((uint32_t)((ws ^ wb) * NJ) << 6) + (uint32_t)lane;
+        T u[NJ], nb[NJ];
+        urow(b, u);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nb[j] = rows[j << 6];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = fma_t(Lb * u[j], nb[j], acc[j]);
       }
       if (b0 >= 0) take(b0, n0);
       if (b1 >= 0) take(b1, n1);
@@ -671,6 +712,15 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
     }
     // y is not read again by this launch: it leaves through LDS as 16-byte write-through stores that do not stay in
     // the XCD's L2, which keeps the p tiles that later tiles read as neighbours
+#if MMHN_KV_DIRECT
+    // (variant: 8-byte write-through stores straight from the accumulators, no trip through LDS)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      T* dst = y + base + xhi + ((((uint32_t)(wave * NJ + j)) << 6) | (uint32_t)lane);
+      if (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc[j]) : "memory");
+      else *dst = acc[j];
+    }
+#else
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) tile[((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane] = acc[j];
@@ -680,6 +730,7 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
       T* dst = y + base + xhi + e;
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
     }
+#endif
     if (it + 1 < tpw) __syncthreads();                       // the tile (and hx) are rewritten by the next trip
   }
 }
