@@ -105,6 +105,7 @@ struct Batch {
   DevArr<int> d_sp_list[2][SP_NCLASS];
   bool sp_ok = false;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
+  int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
   std::vector<uint32_t> ptiles;
   DevArr<int> d_ptoff;
@@ -357,8 +358,10 @@ struct Engine : EngineBase {
       HIPCHECK(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     }
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve2<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -567,9 +570,12 @@ struct Engine : EngineBase {
       const size_t lds = psolve2_lds(mk) + (size_t)dl_cap * sizeof(T);
 #endif
       const double bytes = (double)b.ptiles.size() * (double)(1 << TB) * sizeof(T);
+      const bool dlok = b.max_dl <= dl_cap;       // every patient's dP / dM tile slices fit the dl area: branch-free instantiation
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-        if (tr) hipLaunchKernelGGL((k_psolve2<T, true>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
-        else hipLaunchKernelGGL((k_psolve2<T, false>), dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap);
+#define PS2_ARGS dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap
+        if (tr) { if (dlok) hipLaunchKernelGGL((k_psolve2<T, true, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, true, false>), PS2_ARGS); }
+        else { if (dlok) hipLaunchKernelGGL((k_psolve2<T, false, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, false, false>), PS2_ARGS); }
+#undef PS2_ARGS
       });
       return;
     }
@@ -731,6 +737,7 @@ struct Engine : EngineBase {
         add_tiles(cur.mapJ, pr.j, dj.k);
         cur.maxkJ = std::max(cur.maxkJ, dj.k);
         cur.maxkcJ = std::max(cur.maxkcJ, std::max(popc(dj.maskP), popc(dj.maskM)));
+        cur.max_dl = std::max(cur.max_dl, (1 << popc(dj.maskP & ((1u << TB) - 1u))) + (1 << popc(dj.maskM & ((1u << TB) - 1u))));
         cur.dJ.push_back(dj);
       }
       if (has0) {

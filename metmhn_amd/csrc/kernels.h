@@ -1459,7 +1459,7 @@ __device__ __forceinline__ T cluster_bcast(T v, int src) {
 #else
 #define PS2_WPE TSB_WPE
 #endif
-template <typename T, bool TR>
+template <typename T, bool TR, bool DLOK>
 __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict__ descs,
                                                     const int* __restrict__ pt_off,
                                                     const uint32_t* __restrict__ ptiles,
@@ -1520,7 +1520,8 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
   const T* dM = dP + (1ll << __popc(maskP));
   const T* dE = dM + (1ll << __popc(maskM));
   const int nPin = __popc(cP), nMin = __popc(cM);
-  const bool dl_ok = (1 << nPin) + (1 << nMin) <= dl_cap;
+  // DLOK (chosen by the host for the launch): every patient's dP / dM slices of a tile fit the dl area of LDS
+  const bool dl_ok = DLOK || (1 << nPin) + (1 << nMin) <= dl_cap;
   const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
   JLink<T> Lk;
   if (rhs_mode == 3) Lk = links[prob];
@@ -1738,13 +1739,16 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
           }
           // the lane's own states: position in the tile slices of the diagonal tables; its in-group coefficients
           // coefficient ids: 0 = bit 0 out of (0, jh 0), 1 = bit 0 out of (0, jh 1), 2 = bit HB out of (jl 0, 0), 3 = out of (jl 1, 0)
+          // (all index look-ups of the group first, then everything that hangs on them: one LDS round trip each instead
+          // of one per state)
           T dsum[OWN], cmine[OWN];
+          uint32_t iP[OWN], iM[OWN];
 #pragma unroll
           for (int o = 0; o < OWN; ++o) {
             const uint32_t jq = slot + (uint32_t)(o * HP);
             const uint32_t slo = ulo | (jq & (NL - 1)), shi = uhi | ((jq >> GL) << 5);
-            const uint32_t iP = pxt[slo] | pxt[64 + shi], iM = pxt[128 + slo] | pxt[192 + shi];
-            dsum[o] = dl_ok ? dl[iP] + dl[(1 << nPin) + iM] : dP[hP | iP] + dM[hM | iM];
+            iP[o] = pxt[slo] | pxt[64 + shi];
+            iM[o] = pxt[128 + slo] | pxt[192 + shi];
           }
           auto coefs = [&]() {
 #pragma unroll
@@ -1756,6 +1760,9 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
           };
           constexpr bool CLATE = MMHN_Q_CLATE < 0 ? HP == 1 : MMHN_Q_CLATE != 0;   // coefficients after the move loop (registers)
           if (!CLATE) coefs();
+#pragma unroll
+          for (int o = 0; o < OWN; ++o)
+            dsum[o] = (DLOK || dl_ok) ? dl[iP[o]] + dl[(1 << nPin) + iM[o]] : dP[hP | iP[o]] + dM[hM | iM[o]];
           uint32_t todo = TR ? (~ub & BMASK) : ub;
 #pragma unroll
           for (int i = 1; i < HP; ++i) if (slot >= (uint32_t)i) todo &= todo - 1;
