@@ -1052,6 +1052,10 @@ __device__ unsigned long long g_stamps[16];
 #ifndef MMHN_Q_TPA
 #define MMHN_Q_TPA 2          // neighbour tiles in flight per thread in k_psolve2's step A
 #endif
+#ifndef MMHN_Q_EARLY
+#define MMHN_Q_EARLY 0        // 1: first trip of neighbour-tile loads requested before the per-tile set-up barriers (measured: the
+                              // values spill across the set-up at 64 VGPRs - 68 B scratch, 27.8 instead of 22.3 ms; one tile ahead: 23.2 ms)
+#endif
 #ifndef MMHN_Q_CLATE
 #define MMHN_Q_CLATE -1
 #endif
@@ -1579,6 +1583,36 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
     const uint32_t nlo = ((uint32_t)tid & LOM) << GL, nhi = (uint32_t)tid >> (6 - GL);
     // ---- per tile: slices of the diagonal tables (land in LDS behind the next barrier), tile-bit factors
     // (up to 2^10 + 2^4 entries: thread tid takes entry tid and, for the few beyond the workgroup size, tid + TSB)
+    // ---- single-bit moves above the tile (step A): scalar bit list of the tile index.  With MMHN_Q_EARLY the first
+    // MMHN_Q_TPA neighbour tiles that come from HBM are requested here - they were solved at least two tiles ago, their
+    // stores were waited for at the previous tile's barrier - and fly through the set-up barriers below
+    uint32_t mb = (TR ? ~H : H) & ((1u << (k - t)) - 1u) & ~(1u << (seedb - t));
+    const uint32_t dprev = H ^ Hprev;
+    const bool prev_in_lds = Hprev != 0xffffffffu && (dprev & (dprev - 1)) == 0 && (dprev & mb);
+    if (prev_in_lds) mb &= ~dprev;
+    constexpr int TPA = MMHN_Q_TPA;
+    auto nbr_fetch = [&](int (&bq)[TPA], lvec_t (&nv)[TPA][2]) {
+#pragma unroll
+      for (int q = 0; q < TPA; ++q) {
+        const bool on = mb != 0;                               // wave-uniform
+        bq[q] = on ? t + __ffs(mb) - 1 : -1;
+        mb &= mb - 1;
+        if (on) {
+#ifdef MMHN_ABL_FAKE_NBR      // timing-only ablation (wrong results): neighbour reads served by L2 instead of HBM
+          const T* yn = y + base + ((uint32_t)tid << GL);
+#else
+          const T* yn = y + base + (xhi ^ (1u << bq[q])) + ((uint32_t)tid << GL);
+#endif
+          nv[q][0] = *reinterpret_cast<const lvec_t*>(yn);
+          nv[q][1] = *reinterpret_cast<const lvec_t*>(yn + (1u << HB));
+        }
+      }
+    };
+#if MMHN_Q_EARLY
+    int bq0[TPA];
+    lvec_t nv0[TPA][2];
+    nbr_fetch(bq0, nv0);
+#endif
     T dval = 0, dval2 = 0;
     const int ndl = dl_ok ? (1 << nPin) + (1 << nMin) : 0;
     auto dl_fetch = [&](int e) {
@@ -1627,45 +1661,15 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
     }
     __syncthreads();                                   // Utab complete; the previous tile's stores have landed
     STAMP(1);
-    // ---- step A: single-bit moves above the tile apply to every state; scalar bit list of the tile index
+    // ---- step A: single-bit moves above the tile apply to every state
     {
-      uint32_t mb = (TR ? ~H : H) & ((1u << (k - t)) - 1u) & ~(1u << (seedb - t));
       auto add_move = [&](int b, const T (&nf)[NJ]) {
         const lvec_t Lv = *reinterpret_cast<const lvec_t*>(Ltab + b * 64 + nlo);
         const T U0 = Utab[b * 64 + nhi], U1 = Utab[b * 64 + nhi + 32];
 #pragma unroll
         for (int jq = 0; jq < NJ; ++jq) acc[jq] += Lv.v[jq & (NL - 1)] * ((jq >> GL) ? U1 : U0) * nf[jq];
       };
-      // the tile this workgroup solved last is still in LDS (this thread's own group)
-      const uint32_t dprev = H ^ Hprev;
-      if (Hprev != 0xffffffffu && (dprev & (dprev - 1)) == 0 && (dprev & mb)) {
-        const group_t gq = *reinterpret_cast<const group_t*>(yt + ((uint32_t)tid << G));
-        T nf[NJ];
-#pragma unroll
-        for (int jq = 0; jq < NJ; ++jq) nf[jq] = gq.v[jq];
-        add_move(t + __ffs(dprev) - 1, nf);
-        mb &= ~dprev;
-      }
-      // the others stream from HBM, TPA neighbour tiles in flight per thread
-      constexpr int TPA = MMHN_Q_TPA;
-      while (mb) {
-        int bq[TPA];
-        lvec_t nv[TPA][2];
-#pragma unroll
-        for (int q = 0; q < TPA; ++q) {
-          const bool on = mb != 0;                             // wave-uniform
-          bq[q] = on ? t + __ffs(mb) - 1 : -1;
-          mb &= mb - 1;
-          if (on) {
-#ifdef MMHN_ABL_FAKE_NBR      // timing-only ablation (wrong results): neighbour reads served by L2 instead of HBM
-            const T* yn = y + base + ((uint32_t)tid << GL);
-#else
-            const T* yn = y + base + (xhi ^ (1u << bq[q])) + ((uint32_t)tid << GL);
-#endif
-            nv[q][0] = *reinterpret_cast<const lvec_t*>(yn);
-            nv[q][1] = *reinterpret_cast<const lvec_t*>(yn + (1u << HB));
-          }
-        }
+      auto nbr_take = [&](const int (&bq)[TPA], const lvec_t (&nv)[TPA][2]) {
 #pragma unroll
         for (int q = 0; q < TPA; ++q) {
           if (bq[q] >= 0) {
@@ -1675,6 +1679,24 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
             add_move(bq[q], nf);
           }
         }
+      };
+      // the tile this workgroup solved last is still in LDS (this thread's own group)
+      if (prev_in_lds) {
+        const group_t gq = *reinterpret_cast<const group_t*>(yt + ((uint32_t)tid << G));
+        T nf[NJ];
+#pragma unroll
+        for (int jq = 0; jq < NJ; ++jq) nf[jq] = gq.v[jq];
+        add_move(t + __ffs(dprev) - 1, nf);
+      }
+      // the others stream from HBM, TPA neighbour tiles in flight per thread
+#if MMHN_Q_EARLY
+      nbr_take(bq0, nv0);
+#endif
+      while (mb) {
+        int bq[TPA];
+        lvec_t nv[TPA][2];
+        nbr_fetch(bq, nv);
+        nbr_take(bq, nv);
       }
       if (!TR && seed_move_possible(lone, pairP, xhi, tmask)) {
         // seeding into this tile: only the PT == MT states of the seed = 0 part carry values (and only they were
