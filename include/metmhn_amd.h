@@ -59,6 +59,13 @@ int mmhn_score_and_grad(mmhn_handle h, const double* log_theta, const double* lo
                         double* d_dp, double* d_dm);
 int mmhn_cohort_sums(mmhn_handle h, const double* log_theta, const double* log_d_p,
                      const double* log_d_m, int with_grad, double* sums);
+/* The same in two halves: _begin issues the evaluation (and the all-reduce) and returns without waiting - the
+ * parameter arrays may be reused at once -, _end waits and delivers.  In between the caller is free to do host work: the
+ * reference computes its penalty terms on the host after the score (regularized_optimization.py:292-298), here they run
+ * next to the GPU.  One evaluation in flight per handle. */
+int mmhn_cohort_sums_begin(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                           const double* log_d_m, int with_grad);
+int mmhn_cohort_sums_end(mmhn_handle h, double* sums);
 /* per-patient results of the current cohort (tests): lp[n_pat], and if non-NULL
  * d_theta[n_pat][N*N], d_dp[n_pat][N], d_dm[n_pat][N]  (ssr._g_coupled_*, _grad_*_obs) */
 int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log_d_p,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "mmhn_score": [C.c_void_p, f64p, f64p, f64p, C.c_double, f64p],
     "mmhn_score_and_grad": [C.c_void_p, f64p, f64p, f64p, C.c_double, f64p, f64p, f64p, f64p],
     "mmhn_cohort_sums": [C.c_void_p, f64p, f64p, f64p, C.c_int, f64p],
+    "mmhn_cohort_sums_begin": [C.c_void_p, f64p, f64p, f64p, C.c_int],
+    "mmhn_cohort_sums_end": [C.c_void_p, f64p],
     "mmhn_patient_grads": [C.c_void_p, f64p, f64p, f64p, f64p, f64p, f64p, f64p],
     "mmhn_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
     "mmhn_kron_diag": [C.c_void_p, f64p, i8p, f64p],

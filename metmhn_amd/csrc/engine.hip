@@ -1009,6 +1009,8 @@ struct Engine : EngineBase {
                                b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
           }
           HIPCHECK(hipGetLastError());
+          // (its own launch: folded into k_pclass it cost more than the launch - k_pclass 20.5 -> 21.9 ms on the bench
+          // cohort, the LUAD evaluation +25 us)
           hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
           HIPCHECK(hipGetLastError());
           launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p, -1, b.d_grcJ, DJ.p, gjs);
@@ -1055,10 +1057,14 @@ struct Engine : EngineBase {
   // sums layout of the C ABI (include/metmhn_amd.h): packed on the device, summed over the ranks of the
   // communicator (one RCCL all-reduce on this stream, regularized_optimization.py:256-266 needs nothing else),
   // then one download and one synchronisation per evaluation
-  // (A hipGraph replay of the evaluation was measured on the LUAD-reduced cohort, ROCm 7.0.2: the host is free after
-  // 75 us instead of 535 us, but the graph takes 660 us to execute against 550 us for the eager launches - dropped.)
-  void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
-    auto t0 = std::chrono::steady_clock::now();
+  // begin: everything is issued (evaluation, packing, the all-reduce, the download into pinned memory), nothing is
+  // waited for - the caller's host work (the reference computes its penalty terms on the host after the score,
+  // regularized_optimization.py:296) runs next to the GPU; end: wait and copy out.
+  bool sums_pending = false;
+  std::chrono::steady_clock::time_point sums_t0, sums_issued;
+  void cohort_sums_begin(const double* lt, const double* ldp, const double* ldm, bool grad) {
+    REQUIRE(!sums_pending, "mmhn_cohort_sums_begin: the previous evaluation has not been collected");
+    sums_t0 = std::chrono::steady_clock::now();
     const int total = 4 + 2 * N * N + 3 * N;
     abi_sums.alloc(total);
     if (!h_abi) HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)total * sizeof(double), hipHostMallocDefault));
@@ -1067,15 +1073,26 @@ struct Engine : EngineBase {
     HIPCHECK(hipGetLastError());
     if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
     HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
-    const auto t_issued = std::chrono::steady_clock::now();
+    sums_issued = std::chrono::steady_clock::now();
+    sums_pending = true;
+  }
+  void cohort_sums_end(double* o) {
+    REQUIRE(sums_pending, "mmhn_cohort_sums_end without mmhn_cohort_sums_begin");
+    sums_pending = false;
     HIPCHECK(hipStreamSynchronize(stream));
-    std::memcpy(o, h_abi, total * sizeof(double));
+    std::memcpy(o, h_abi, (size_t)(4 + 2 * N * N + 3 * N) * sizeof(double));
     static const bool trace_host = std::getenv("MMHN_TRACE_HOST") != nullptr;   // diagnostic: host time to issue vs total
     if (trace_host)
-      std::fprintf(stderr, "[mmhn] evaluation issued after %.1f us, complete after %.1f us%s\n",
-                   std::chrono::duration<double, std::micro>(t_issued - t0).count(),
-                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), "");
-    finish_eval(t0);
+      std::fprintf(stderr, "[mmhn] evaluation issued after %.1f us, complete after %.1f us\n",
+                   std::chrono::duration<double, std::micro>(sums_issued - sums_t0).count(),
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - sums_t0).count());
+    finish_eval(sums_t0);
+  }
+  // (A hipGraph replay of the evaluation was measured on the LUAD-reduced cohort, ROCm 7.0.2: the host is free after
+  // 75 us instead of 535 us, but the graph takes 660 us to execute against 550 us for the eager launches - dropped.)
+  void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
+    cohort_sums_begin(lt, ldp, ldm, grad);
+    cohort_sums_end(o);
   }
 
   void comm_init(const ncclUniqueId& id, int rank, int nranks) {
@@ -1454,6 +1471,22 @@ int mmhn_cohort_sums(mmhn_handle h, const double* lt, const double* ldp, const d
   GUARD(h);
   REQUIRE(lt && ldp && ldm && sums, "null pointer");
   DISPATCH(h, cohort_sums(lt, ldp, ldm, with_grad != 0, sums));
+  API_END
+}
+
+int mmhn_cohort_sums_begin(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, int with_grad) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(lt && ldp && ldm, "null pointer");
+  DISPATCH(h, cohort_sums_begin(lt, ldp, ldm, with_grad != 0));
+  API_END
+}
+
+int mmhn_cohort_sums_end(mmhn_handle h, double* sums) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(sums, "null pointer");
+  DISPATCH(h, cohort_sums_end(sums));
   API_END
 }
 

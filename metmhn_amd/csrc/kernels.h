@@ -2318,6 +2318,40 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   }
 }
 
+// eq block (seed = 0 states with PT == MT): subsets e of the paired events, x0 = both bits
+//   slot 0      -p[x0] q[x0]
+//   slot 1 + l   p[x0] q[x0 | pair_l]          (pair_l not in e)
+//   slot ke + 1  p[x0] q[x0 | seedbit]         (0 if seeding inactive)
+template <typename T>
+__device__ __forceinline__ void eq_flows_body(const Desc& d, const T* __restrict__ p, const T* __restrict__ q, T* A, int tid,
+                                              int nthreads) {
+  const int ke = __popc(d.pairP);
+  T* out = A + d.aoff + class_block_size(__popc(d.maskP)) + class_block_size(__popc(d.maskM));
+  const long long items = (long long)(ke + 2) << ke;
+  for (long long it = tid; it < items; it += nthreads) {
+    const int slot = (int)(it >> ke);
+    const uint32_t e = (uint32_t)(it & ((1ll << ke) - 1));
+    const uint32_t xp = pdep32(e, d.pairP);
+    const uint32_t x0 = xp | (xp << 1);
+    T v;
+    if (slot == 0) {
+      v = -p[d.off + x0] * q[d.off + x0];
+    } else if (slot <= ke) {
+      const uint32_t bp = pdep32(1u << (slot - 1), d.pairP);
+      v = (x0 & bp) ? T(0) : p[d.off + x0] * q[d.off + (x0 | bp | (bp << 1))];
+    } else {
+      v = d.seedbit >= 0 ? p[d.off + x0] * q[d.off + (x0 | (1u << d.seedbit))] : T(0);
+    }
+    out[it] = v;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_eq_flows(const Desc* __restrict__ dJ,
+                                                    const T* __restrict__ p,
+                                                    const T* __restrict__ q, T* A) {
+  eq_flows_body(dJ[blockIdx.x], p, q, A, (int)threadIdx.x, BLOCK);
+}
+
 // ------------------------------------------------------------------------------------
 // k_pclass: the class marginals of k_class_marg, one workgroup per PATIENT, accumulated in registers.
 //
@@ -2491,38 +2525,6 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
     };
     if (nh == 0) block(std::false_type{}, 0u);
     else for (uint32_t Shi = 0; Shi < (1u << nh); ++Shi) block(std::true_type{}, Shi);
-  }
-}
-
-// eq block (seed = 0 states with PT == MT): subsets e of the paired events, x0 = both bits
-//   slot 0      -p[x0] q[x0]
-//   slot 1 + l   p[x0] q[x0 | pair_l]          (pair_l not in e)
-//   slot ke + 1  p[x0] q[x0 | seedbit]         (0 if seeding inactive)
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_eq_flows(const Desc* __restrict__ dJ,
-                                                    const T* __restrict__ p,
-                                                    const T* __restrict__ q, T* A) {
-  const Desc& d = dJ[blockIdx.x];
-  const int ke = __popc(d.pairP);
-  T* out = A + d.aoff + class_block_size(__popc(d.maskP)) + class_block_size(__popc(d.maskM));
-  const long long items = (long long)(ke + 2) << ke;
-  const uint32_t pm3 = d.pairP | (d.pairP << 1);
-  for (long long it = threadIdx.x; it < items; it += BLOCK) {
-    const int slot = (int)(it >> ke);
-    const uint32_t e = (uint32_t)(it & ((1ll << ke) - 1));
-    const uint32_t xp = pdep32(e, d.pairP);
-    const uint32_t x0 = xp | (xp << 1);
-    T v;
-    if (slot == 0) {
-      v = -p[d.off + x0] * q[d.off + x0];
-    } else if (slot <= ke) {
-      const uint32_t bp = pdep32(1u << (slot - 1), d.pairP);
-      v = (x0 & bp) ? T(0) : p[d.off + x0] * q[d.off + (x0 | bp | (bp << 1))];
-    } else {
-      v = d.seedbit >= 0 ? p[d.off + x0] * q[d.off + (x0 | (1u << d.seedbit))] : T(0);
-    }
-    (void)pm3;
-    out[it] = v;
   }
 }
 

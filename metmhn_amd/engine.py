@@ -111,6 +111,16 @@ class Engine:
         _lib.check(self.lib.mmhn_cohort_sums(self.h, a, b, c, int(bool(with_grad)), sums.ctypes.data_as(f64p)))
         return sums
 
+    def cohort_sums_begin(self, log_theta, log_d_p, log_d_m, with_grad=True):
+        """Issue the evaluation and return at once (mmhn_cohort_sums_begin); collect with cohort_sums_end()."""
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        _lib.check(self.lib.mmhn_cohort_sums_begin(self.h, a, b, c, int(bool(with_grad))))
+
+    def cohort_sums_end(self):
+        sums = np.zeros(4 + 2 * self.N * self.N + 3 * self.N)
+        _lib.check(self.lib.mmhn_cohort_sums_end(self.h, sums.ctypes.data_as(f64p)))
+        return sums
+
     def patient_grads(self, log_theta, log_d_p, log_d_m, with_grad=True):
         keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
         P, N = self.n_pat, self.N

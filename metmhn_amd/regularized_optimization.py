@@ -114,13 +114,19 @@ def _engine_for(dat) -> Engine:
     return eng
 
 
-def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool):
+def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool, meanwhile: Callable = None):
     """Cohort-wide partial sums: this rank's shard, combined over the ranks by ONE all-reduce - inside the library
-    on the engine's stream (RCCL) when the communicator is attached, else through torch.distributed."""
-    sums = eng.cohort_sums(log_theta, log_d_p, log_d_m, with_grad=with_grad)
+    on the engine's stream (RCCL) when the communicator is attached, else through torch.distributed.
+    `meanwhile()` (host work that does not need the result: the penalty terms) runs while the GPU evaluates;
+    returns (sums, meanwhile's result)."""
+    eng.cohort_sums_begin(log_theta, log_d_p, log_d_m, with_grad=with_grad)
+    try:
+        aside = meanwhile() if meanwhile is not None else None
+    finally:
+        sums = eng.cohort_sums_end()
     if eng._sharded and not eng._device_comm:
         sums = _dist.allreduce_sums(sums)
-    return sums
+    return sums, aside
 
 
 # ---- penalties (host NumPy, as in the reference; regularized_optimization.py:11-52) ----
@@ -167,13 +173,13 @@ def symmetric_penal(params, n_total: int, eps=1e-05):
 def score(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """Log-likelihood of the dataset (regularized_optimization.py:55-130)."""
     eng = _engine_for(dat)
-    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, False), eng.N, perc_met)[0]
+    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, False)[0], eng.N, perc_met)[0]
 
 
 def score_and_grad(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """(score, d_theta, d_d_p, d_d_m)  (regularized_optimization.py:163-267)."""
     eng = _engine_for(dat)
-    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, True), eng.N, perc_met)
+    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, True)[0], eng.N, perc_met)
 
 
 def _unpack(params, n_total):
@@ -186,8 +192,9 @@ def score_reg(params, dat, perc_met: float, penal: Callable, w_penal: float):
     """regularized_optimization.py:133-160."""
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
-    sc = score(th, dp, dm, dat, perc_met)
-    pen, _ = penal(params, n_total)
+    eng = _engine_for(dat)
+    sums, (pen, _) = _sums(eng, th, dp, dm, False, meanwhile=lambda: penal(params, n_total))    # penalty next to the GPU
+    sc = _dist.combine_sums(sums, eng.N, perc_met)[0]
     return np.array(-sc + w_penal * pen)
 
 
@@ -195,9 +202,10 @@ def score_and_grad_reg(params, dat, perc_met: float, penal: Callable, w_penal: f
     """regularized_optimization.py:270-298."""
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
-    sc, d_th, d_d_p, d_d_m = score_and_grad(th, dp, dm, dat, perc_met)
+    eng = _engine_for(dat)
+    sums, (pen, pen_) = _sums(eng, th, dp, dm, True, meanwhile=lambda: penal(params, n_total))  # penalty next to the GPU
+    sc, d_th, d_d_p, d_d_m = _dist.combine_sums(sums, eng.N, perc_met)
     grad_vec = np.concatenate((d_th.flatten(), d_d_p, d_d_m))
-    pen, pen_ = penal(params, n_total)
     return np.array(-sc + w_penal * pen), -grad_vec + w_penal * pen_
 
 

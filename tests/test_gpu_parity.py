@@ -790,3 +790,24 @@ def test_staged_and_fused_small_paths_agree(monkeypatch, golden):
             np.testing.assert_allclose(gt, g[pre + "d_th"], **TIGHT)
             np.testing.assert_allclose(gp, g[pre + "d_dp"], **TIGHT)
             np.testing.assert_allclose(gm, g[pre + "d_dm"], **TIGHT)
+
+
+@pytest.mark.gpu
+def test_split_evaluation_and_error_order(golden):
+    """mmhn_cohort_sums_begin / _end: same sums as the one-call form, host work in between, misuse is an error."""
+    from metmhn_amd import Engine
+    g = golden("cohorts")
+    lt, dp, dm, dat = g["c1_log_theta"], g["c1_log_d_p"], g["c1_log_d_m"], g["c1_dat"]
+    e = Engine((dat.shape[1] - 3) // 2)
+    e.set_cohort(dat)
+    ref = e.cohort_sums(lt, dp, dm)
+    e.cohort_sums_begin(lt, dp, dm)
+    lt2 = lt.copy()                                           # the parameter arrays may be reused at once
+    lt2[:] = 0.0
+    with pytest.raises(RuntimeError):
+        e.cohort_sums_begin(lt, dp, dm)                       # one evaluation in flight per handle
+    np.testing.assert_array_equal(e.cohort_sums_end(), ref)
+    with pytest.raises(RuntimeError):
+        e.cohort_sums_end()
+    np.testing.assert_array_equal(e.cohort_sums(lt, dp, dm), ref)
+    e.close()
