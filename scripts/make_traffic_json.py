@@ -31,7 +31,7 @@ def main():
     out = {"_comment": __doc__.strip().split("\n\n")[1].replace("\n", " ")}
     ef, ew = per_launch("eval_f", "FETCH_SIZE"), per_launch("eval_w", "WRITE_SIZE")
     ek = {}
-    for name, kern in (("psolve_fwd", "k_psolve2<double, false>"), ("psolve_adj", "k_psolve2<double, true>"), ("pclass", "k_pclass<double>")):
+    for name, kern in (("psolve_fwd", "k_psolve2<double, false, true>"), ("psolve_adj", "k_psolve2<double, true, true>"), ("pclass", "k_pclass<double>")):
         if kern not in ef:
             continue
         b = (2 * ef[kern] + ew[kern]) * 1024
