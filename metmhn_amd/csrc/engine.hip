@@ -397,24 +397,27 @@ struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- parameters
   void build_params(const double* lt, const double* ldp, const double* ldm) {
-    std::vector<double> zero(N, 0.0);
-    if (!ldp) ldp = zero.data();
-    if (!ldm) ldm = zero.data();
+    // exp(theta_ij - d_j) = exp(theta_ij) * exp(-d_j): N^2 + 2N exponentials per evaluation instead of 3 N^2 (this runs
+    // on the host before the first launch of every evaluation - 26 us of a 400 us LUAD evaluation as three full passes)
+    std::vector<double> eth((size_t)N * N), enp(N, 1.0), enm(N, 1.0);
+    for (int e = 0; e < N * N; ++e) eth[e] = std::exp(lt[e]);
+    if (ldp) for (int j = 0; j < N; ++j) enp[j] = std::exp(-ldp[j]);
+    if (ldm) for (int j = 0; j < N; ++j) enm[j] = std::exp(-ldm[j]);
     for (int s = 0; s < NPSET; ++s) {
       Params<T>& P = h_par[s];
       std::memset(&P, 0, sizeof(P));
       for (int i = 0; i < N; ++i) {
         for (int j = 0; j < N; ++j) {
-          double v = lt[i * N + j];
-          if (s == PS_PRIM && j == n && i < n) v = 0.0;             // likelihood.py:313
-          if (s == PS_MET && i != j) v -= ldm[j];                   // kronvec.py:18
-          if (s == PS_PRIM && i != j) v -= ldp[j];
-          P.th[i][j] = (T)std::exp(v);
+          double v = eth[i * N + j];
+          if (s == PS_PRIM && j == n && i < n) v = 1.0;             // likelihood.py:313
+          if (s == PS_MET && i != j) v *= enm[j];                   // kronvec.py:18
+          if (s == PS_PRIM && i != j) v *= enp[j];
+          P.th[i][j] = (T)v;
         }
-        P.baseP[i] = (T)std::exp(lt[i * N + i]);
-        P.baseM[i] = i < n ? (T)(std::exp(lt[i * N + i]) * std::exp(lt[i * N + n])) : (T)0;
-        P.dp[i] = (T)std::exp(ldp[i]);
-        P.dm[i] = (T)std::exp(ldm[i]);
+        P.baseP[i] = (T)eth[i * N + i];
+        P.baseM[i] = i < n ? (T)(eth[i * N + i] * eth[i * N + n]) : (T)0;
+        P.dp[i] = (T)(ldp ? std::exp(ldp[i]) : 1.0);
+        P.dm[i] = (T)(ldm ? std::exp(ldm[i]) : 1.0);
       }
     }
     HIPCHECK(hipMemcpyAsync(d_par.p, h_par, NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
