@@ -1,5 +1,5 @@
 // Host cost of HIP launches, event records and cross-stream waits on the GPU box (small cohorts):
-//   hipcc -O2 --offload-arch=gfx950 -Wno-unused-result -o build_ab/launchcost scripts/launchcost.hip
+//   hipcc -O2 --offload-arch=gfx950 -Wno-unused-value -o build_ab/launchcost scripts/launchcost.hip
 //   gpurun -- './build_ab/launchcost'
 // Measured (MI355X box, ROCm 7.0.2): launch 3 - 5 us, hipMemsetAsync 4 us, timing-event pair around a launch +10 us,
 // fork / launch / join / launch across two streams (4 event operations) 33 - 36 us.
