@@ -930,10 +930,10 @@ struct Engine : EngineBase {
       DJ.p = GJ.p + up4(3 * gjs);
       Abuf.p = DJ.p + up4(3ll * nJ * N);
       if (grad && nJ) zero(zarena.p, zarena_elems(nJ, b.asize, N));
+      prep(b.d_dJ.p, nJ, tabJ.p);                          // (first: the head of the critical chain)
       // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
-      // start now on the side streams, next to the joint forward solve; the assembly waits for them
+      // start now on a side stream, next to the joint forward solve; the assembly waits for them
       if (fused_small) small_classes(b, 0, grad);
-      prep(b.d_dJ.p, nJ, tabJ.p);
       if (!fused_small) prep(b.d_dS.p, nS, tabS.p);        // (k_spatient builds its own tables in LDS)
       const bool per_patient = !use_jacobi && nJ >= psolve_min;
       // the tile-level substitution solver skips dead tiles and its consumers read them: those parts of pi / q_J
