@@ -638,6 +638,7 @@ struct Engine : EngineBase {
   void set_cohort(const int8_t* d_, long long np, int nc) {
     REQUIRE(nc == 2 * n + 3, "dat must have 2*n_mut+3 columns");
     REQUIRE(np >= 0, "negative patient count");
+    REQUIRE(!sums_pending, "mmhn_set_cohort: an evaluation begun with mmhn_cohort_sums_begin has not been collected");
     dat.assign(d_, d_ + np * nc);
     n_pat = np;
     n_cols = nc;
@@ -914,6 +915,7 @@ struct Engine : EngineBase {
 
   void evaluate(const double* lt, const double* ldp, const double* ldm, bool grad, double* host_sums,
                 double* host_out) {
+    REQUIRE(!sums_pending, "an evaluation begun with mmhn_cohort_sums_begin has not been collected");
     auto t0 = std::chrono::steady_clock::now();
     build_params(lt, ldp, ldm);
     const int st = stride();

@@ -806,6 +806,10 @@ def test_split_evaluation_and_error_order(golden):
     lt2[:] = 0.0
     with pytest.raises(RuntimeError):
         e.cohort_sums_begin(lt, dp, dm)                       # one evaluation in flight per handle
+    with pytest.raises(RuntimeError):
+        e.set_cohort(dat)                                     # ... and the cohort stays while it is
+    with pytest.raises(RuntimeError):
+        e.patient_grads(lt, dp, dm)
     np.testing.assert_array_equal(e.cohort_sums_end(), ref)
     with pytest.raises(RuntimeError):
         e.cohort_sums_end()
