@@ -104,6 +104,8 @@ struct Batch {
   std::vector<int> sp_list[2][SP_NCLASS];
   DevArr<int> d_sp_list[2][SP_NCLASS];
   bool sp_ok = false;
+  std::vector<int> paired;       // patients with a joint problem (k_gather_marg runs over these only)
+  DevArr<int> d_paired;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
@@ -806,6 +808,9 @@ struct Engine : EngineBase {
       }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
       b.sp_ok = !b.dS.empty();
+      b.paired.clear();
+      for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) if (b.pats[pi_].j >= 0) b.paired.push_back((int)pi_);
+      up(b.d_paired, b.paired);
       for (int w = 0; w < 2; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) {
         const PatRec& pr = b.pats[pi_];
@@ -960,8 +965,8 @@ struct Engine : EngineBase {
       // 3 marginal right-hand sides
       if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ) {
-        hipLaunchKernelGGL((k_gather_marg<T>), dim3(npat, 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
-                           b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p);
+        hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.paired.size(), 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
+                           b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_paired.p);
         HIPCHECK(hipGetLastError());
       }
       if (fused_small) {

@@ -2056,9 +2056,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
                                                        const Desc* __restrict__ dJ,
                                                        const Desc* __restrict__ dS,
                                                        const Params<T>* __restrict__ par,
-                                                       const T* __restrict__ pi, T* rhsS, JLink<T>* links) {
+                                                       const T* __restrict__ pi, T* rhsS, JLink<T>* links,
+                                                       const int* __restrict__ paired) {
   __shared__ Desc djs;                                     // (the descriptor loops below must not be chains of global loads)
-  const PatRec pr = pats[blockIdx.x];
+  const PatRec pr = pats[paired[blockIdx.x]];              // grid.x = the paired patients of the batch only
   const int part = blockIdx.y;
   const int sp = part == 0 ? pr.s[0] : pr.s[1];
   if (pr.j < 0) return;
