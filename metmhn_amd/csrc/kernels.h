@@ -689,7 +689,9 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
         const bool ss = seed_set(d, x);
         const bool e0x = eq_noseed(d, x);
         T a = 0;
-        for (int b = 0; b < k; ++b) {
+        // without the seeding and without PT == MT a state has no entries in its row / column at all: true for all but
+        // a handful of states of a seed = 0 tile (2^pairs of 4 096), whose bit loop would otherwise be the launch's tail
+        for (int b = 0; b < ((ss || e0x) ? k : 0); ++b) {
           const uint32_t bit = 1u << b;
           const bool has = (x >> b) & 1u;
           const int c = d.cls[b];
