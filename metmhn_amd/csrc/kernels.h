@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const
 }
 
 #ifndef MMHN_KV_PRE
-#define MMHN_KV_PRE 2          // neighbour tiles k_kv fetches ahead of its LDS terms
+#define MMHN_KV_PRE 2          // neighbour tiles k_kv keeps in flight (3 / 4: 102 / 118 VGPRs, one wave per SIMD less, slower)
 #endif
 #ifndef MMHN_KV_DIRECT
 #define MMHN_KV_DIRECT 1         // y leaves as 8-byte write-through stores straight from the accumulators (0: through LDS as 16-byte stores)
@@ -619,12 +619,16 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
           }
         }
       };
-      T n0[NJ], n1[NJ];
-      int b0 = -1, b1 = -1;
-      if (mvs) { b0 = __ffs(mvs) - 1; mvs &= mvs - 1; fetch(b0, n0); }
-#if MMHN_KV_PRE >= 2
-      if (mvs) { b1 = __ffs(mvs) - 1; mvs &= mvs - 1; fetch(b1, n1); }
-#endif
+      // MMHN_KV_PRE neighbour tiles in flight: requested, the LDS terms run, taken, the next ones requested
+      constexpr int PRE = MMHN_KV_PRE;
+      T nq[PRE][NJ];
+      int bq[PRE];
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) {
+        bq[q] = mvs ? __ffs(mvs) - 1 : -1;                      // (scalar)
+        mvs &= mvs - 1;                                         // 0 stays 0
+        if (bq[q] >= 0) fetch(bq[q], nq[q]);
+      }
       // lane bits: neighbour = other lane of the same row (conflict-free ds_read_b64 from the staged tile)
 #pragma unroll 1
       for (int b = 0; b < 6; ++b) {
@@ -667,16 +671,16 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = fma_t(Lb * u[j], nb[j], acc[j]);
       }
-      if (b0 >= 0) take(b0, n0);
-      if (b1 >= 0) take(b1, n1);
-      while (mvs) {
-        b0 = __ffs(mvs) - 1; mvs &= mvs - 1;
-        b1 = mvs ? __ffs(mvs) - 1 : -1;
-        if (b1 >= 0) mvs &= mvs - 1;
-        fetch(b0, n0);
-        if (b1 >= 0) fetch(b1, n1);
-        take(b0, n0);
-        if (b1 >= 0) take(b1, n1);
+      for (;;) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) if (bq[q] >= 0) take(bq[q], nq[q]);
+        if (!mvs) break;
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+          bq[q] = mvs ? __ffs(mvs) - 1 : -1;
+          mvs &= mvs - 1;
+          if (bq[q] >= 0) fetch(bq[q], nq[q]);
+        }
       }
     } else {
       // generic path (seeding bit inside the tile, or a seed = 0 tile with PT == MT states): per-state conditions
