@@ -476,6 +476,9 @@ __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const
 #ifndef MMHN_KV_PRE
 #define MMHN_KV_PRE 2          // neighbour tiles k_kv keeps in flight (3 / 4: 102 / 118 VGPRs, one wave per SIMD less, slower)
 #endif
+#ifndef MMHN_KV_LU
+#define MMHN_KV_LU 2            // lane-bit moves unrolled (3: 98 VGPRs, one wave per SIMD less)
+#endif
 #ifndef MMHN_KV_DIRECT
 #define MMHN_KV_DIRECT 1         // y leaves as 8-byte write-through stores straight from the accumulators (0: through LDS as 16-byte stores)
 #endif
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
         if (bq[q] >= 0) fetch(bq[q], nq[q]);
       }
       // lane bits: neighbour = other lane of the same row (conflict-free ds_read_b64 from the staged tile)
-#pragma unroll 1
+#pragma unroll MMHN_KV_LU
       for (int b = 0; b < 6; ++b) {
         const bool has = (lane >> b) & 1;
         const T Lb = (TR ? !has : has) ? Ltab[b * 64 + lane] * hx[b] : T(0);
