@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SRC = [os.path.join(_HERE, "csrc", f) for f in ("engine.hip", "kernels.h", "desc.h", "sampler.h")]
+import glob
+_SRC = [os.path.join(_HERE, "csrc", "engine.hip")] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")))
 _HDR = os.path.join(_ROOT, "include", "metmhn_amd.h")
 LIB_PATH = os.environ.get("MMHN_LIB", os.path.join(_HERE, "libmetmhn_amd.so"))   # MMHN_LIB: A/B builds
 

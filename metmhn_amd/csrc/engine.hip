@@ -30,6 +30,7 @@
 #include "../../include/metmhn_amd.h"
 #include "kernels.h"
 #include "small.h"
+#include "msolve.h"
 #include "sampler.h"
 
 namespace mmhn {
@@ -106,6 +107,12 @@ struct Batch {
   bool sp_ok = false;
   std::vector<int> paired;       // patients with a joint problem (k_gather_marg runs over these only)
   DevArr<int> d_paired;
+  // matrix path (msolve.h): every joint problem of the batch qualifies -> the solves run in the class-sorted layout
+  bool mpath = false;
+  std::vector<MDesc> md;
+  DevArr<MDesc> d_md;
+  std::vector<int> olist;        // joint problems that stay on the tile kernels
+  DevArr<int> d_olist;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
@@ -305,6 +312,11 @@ struct Engine : EngineBase {
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
+  int msolve_mode = 1;          // MMHN_MSOLVE=0: keep the tile kernels (k_psolve2) for the joint solves of per-patient batches
+  DevArr<T> piM, qM;            // matrix path: solutions in matrix layout
+  DevArr<uint16_t> d_rowT, d_rankT;
+  DevArr<MUnit> d_units;
+  int n_cu = 256;
   // counters
   mmhn_counters cnt{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -346,7 +358,22 @@ struct Engine : EngineBase {
       if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
       if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
+      if (const char* ms = std::getenv("MMHN_MSOLVE")) msolve_mode = std::atoi(ms);
+      std::vector<uint16_t> rt(MROWS), rk(MROWS);
+      matrix_rows(rt.data(), rk.data());
+      d_rowT.alloc(MROWS); d_rankT.alloc(MROWS);
+      HIPCHECK(hipMemcpy(d_rowT.p, rt.data(), MROWS * sizeof(uint16_t), hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(d_rankT.p, rk.data(), MROWS * sizeof(uint16_t), hipMemcpyHostToDevice));
+      std::vector<MUnit> mu(MW * MUPW);
+      matrix_units(mu.data());
+      d_units.alloc(mu.size());
+      HIPCHECK(hipMemcpy(d_units.p, mu.data(), mu.size() * sizeof(MUnit), hipMemcpyHostToDevice));
+      hipDeviceProp_t prop;
+      HIPCHECK(hipGetDeviceProperties(&prop, device));
+      n_cu = std::max(1, prop.multiProcessorCount);
     }
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -566,6 +593,26 @@ struct Engine : EngineBase {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
     const int mk = std::max(b.maxkJ, 1);
+    int nold = nJ;                                              // problems the tile kernels take
+    const int* plist = nullptr;
+    if (b.mpath) {
+      // matrix path: the solution is written once (seeded half)
+      const int nM = (int)b.md.size();
+      double bytes = 0;
+      for (const MDesc& m : b.md) bytes += 0.5 * (double)(1ll << b.dJ[m.prob].k) * sizeof(T);
+      T* ym = tr ? qM.p : piM.p;
+      timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
+        const dim3 g((unsigned)std::min(nM, n_cu)), bk(MTHREADS);
+        const size_t lds = msolve_lds<T>();
+        if (tr) hipLaunchKernelGGL((k_msolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_md.p, nM, d_rowT.p, d_rankT.p, d_units.p, ym, tabJ.p, links.p, qS.p);
+        else hipLaunchKernelGGL((k_msolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_md.p, nM, d_rowT.p, d_rankT.p, d_units.p, ym, tabJ.p, links.p, qS.p);
+      });
+      hipLaunchKernelGGL((k_mconvert<T>), dim3(nM, 64), dim3(MROWS), 0, stream, b.d_dJ.p, b.d_md.p, d_rowT.p, ym, y);
+      HIPCHECK(hipGetLastError());
+      nold = (int)b.olist.size();
+      plist = b.d_olist.p;
+      if (nold == 0) return;
+    }
     if (b.all_multi && psolve_version == 2) {
       const long long spare = (80 * 1024 - 64) - (long long)psolve2_lds(mk);
       const int dl_cap = (int)std::max<long long>(0, std::min<long long>(PS_DL2, spare / (long long)sizeof(T)));
@@ -577,7 +624,7 @@ struct Engine : EngineBase {
       const double bytes = (double)b.ptiles.size() * (double)(1 << TB) * sizeof(T);
       const bool dlok = b.max_dl <= dl_cap;       // every patient's dP / dM tile slices fit the dl area: branch-free instantiation
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-#define PS2_ARGS dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap
+#define PS2_ARGS dim3(nold), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap, plist
         if (tr) { if (dlok) hipLaunchKernelGGL((k_psolve2<T, true, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, true, false>), PS2_ARGS); }
         else { if (dlok) hipLaunchKernelGGL((k_psolve2<T, false, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, false, false>), PS2_ARGS); }
 #undef PS2_ARGS
@@ -588,7 +635,7 @@ struct Engine : EngineBase {
     const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
     const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
     timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-#define PS_ARGS dim3(nJ), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap
+#define PS_ARGS dim3(nold), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap, plist
       if (b.all_multi) {
         if (tr) hipLaunchKernelGGL((k_psolve<T, true, true>), PS_ARGS);
         else hipLaunchKernelGGL((k_psolve<T, false, true>), PS_ARGS);
@@ -671,7 +718,7 @@ struct Engine : EngineBase {
         const int type = row[nc - 1];
         double el = 0;
         if (type == 3) {
-          el = (use_jacobi ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
+          el = (use_jacobi || msolve_mode ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
                (kp + 1) * std::ldexp(1.0, kp) + (km + 1) * std::ldexp(1.0, km) + (ke + 2) * std::ldexp(1.0, ke);
         } else {
           el = 4.0 * std::ldexp(1.0, (type == 2 ? km : kp) + 1);
@@ -730,7 +777,7 @@ struct Engine : EngineBase {
       auto footprint = [&](long long vJ, long long vS, long long as, long long tabs, size_t nJp, size_t nSp, size_t npat) {
         const size_t small = (nSp * (size_t)(N * N + 64 + 1) + nJp * (size_t)(3 * N * N + 3 * N + 64)) * sizeof(T) +
                              nJp * sizeof(JLink<T>) + npat * ((size_t)stride() + 1) * sizeof(double) + npat * 2 * sizeof(T);
-        return (size_t)((use_jacobi ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
+        return (size_t)((use_jacobi || msolve_mode ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
       };
       const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
                                     cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
@@ -765,7 +812,7 @@ struct Engine : EngineBase {
     }
     flush();
     // upload the static descriptions and size the workspace
-    long long mvJ = 0, mvS = 0, mtJ = 0, mtS = 0;
+    long long mvJ = 0, mvS = 0, mtJ = 0, mtS = 0, mvM = 0;
     size_t mZ = 0;
     int bid = 0;
     size_t mnJ = 0, mnS = 0, mp = 0;
@@ -784,6 +831,19 @@ struct Engine : EngineBase {
       b.all_multi = !b.dJ.empty();
       for (const Desc& dj : b.dJ)
         if (!(dj.seedbit >= TB && popc(dj.pairP) <= TB)) b.all_multi = false;
+      b.md.clear();
+      b.olist.clear();
+      b.mpath = msolve_mode != 0 && !use_jacobi && (int)b.dJ.size() >= psolve_min && b.all_multi;
+      if (b.mpath) {
+        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
+          if (!matrix_ok(b.dJ[pj], MCfg<T>::NML, MCfg<T>::KD)) { b.olist.push_back((int)pj); continue; }
+          MDesc m = make_mdesc(b.dJ[pj], (int)pj);
+          b.md.push_back(m);
+        }
+        if (b.md.empty()) b.mpath = false;
+        up(b.d_md, b.md);
+        up(b.d_olist, b.olist);
+      }
       b.mapX.clear();
       for (const int2& m : b.mapJ) {
         const Desc& dj = b.dJ[m.x];
@@ -856,9 +916,11 @@ struct Engine : EngineBase {
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS);
       mZ = std::max<size_t>(mZ, (size_t)zarena_elems((long long)b.dJ.size(), b.asize, N));
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
+      if (b.mpath) mvM = std::max(mvM, b.vecJ);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
     pi.alloc(mvJ); qJ.alloc(mvJ);
+    piM.alloc(mvM); qM.alloc(mvM);
     if (use_jacobi) { lidgJ.alloc(mvJ); rhsJ.alloc(mvJ); }
     links.alloc(std::max<size_t>(mnJ, 1));
     tabJ.alloc(mtJ); tabS.alloc(mtS);

@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
                                                    const uint16_t* __restrict__ perm, int maxk,
                                                    const T* __restrict__ tab,
                                                    const JLink<T>* __restrict__ links,
-                                                   const T* __restrict__ qS, int dl_cap) {
+                                                   const T* __restrict__ qS, int dl_cap,
+                                                    const int* __restrict__ plist) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& d = *reinterpret_cast<Desc*>(smem);
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -1098,7 +1099,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict_
   T* dl = reinterpret_cast<T*>(pml + (1 << TB));                // this tile's slices of the dP / dM tables (dl_cap entries)
   const int tid0 = threadIdx.x;
   int tid = tid0;
-  const int prob = blockIdx.x;
+  const int prob = plist ? plist[blockIdx.x] : (int)blockIdx.x;   // (plist: the batch's problems that stay on the tile kernels)
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = sgpr(d.k);
@@ -1480,7 +1481,8 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
                                                     const uint16_t* __restrict__ perm, int maxk,
                                                     const T* __restrict__ tab,
                                                     const JLink<T>* __restrict__ links,
-                                                    const T* __restrict__ qS, int dl_cap) {
+                                                    const T* __restrict__ qS, int dl_cap,
+                                                    const int* __restrict__ plist) {
   constexpr int NJ = (1 << TB) / TSB;                            // states per thread
   constexpr int G = NJ == 4 ? 2 : NJ == 8 ? 3 : NJ == 2 ? 1 : -1;
   static_assert(G >= 1 && TB == 12, "k_psolve2: 2, 4 or 8 states per thread, 2^12-state tiles");
@@ -1505,7 +1507,7 @@ __global__ __launch_bounds__(TSB, PS2_WPE) void k_psolve2(const Desc* __restrict
   static_assert(NJ == 4, "the four-lanes-per-group in-tile solve is written for 4 states per thread");
   const int tid0 = threadIdx.x;
   int tid = tid0;
-  const int prob = blockIdx.x;
+  const int prob = plist ? plist[blockIdx.x] : (int)blockIdx.x;   // (plist: the batch's problems that stay on the tile kernels)
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = sgpr(d.k);
