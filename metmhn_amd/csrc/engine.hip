@@ -312,7 +312,8 @@ struct Engine : EngineBase {
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
-  int msolve_mode = 1;          // MMHN_MSOLVE=0: keep the tile kernels (k_psolve2) for the joint solves of per-patient batches
+  int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
+                                // second implementation, measured alternative - DESIGN.md 6); default: the tile kernels (k_psolve2)
   DevArr<T> piM, qM;            // matrix path: solutions in matrix layout
   DevArr<uint16_t> d_rowT, d_rankT;
   DevArr<MUnit> d_units;

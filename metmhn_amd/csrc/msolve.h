@@ -30,7 +30,7 @@ namespace mmhn {
 constexpr int MT = MMHN_MT_VALUE;      // thread bits
 constexpr int MROWS = 1 << MT;         // rows = threads of a workgroup
 constexpr int MRB = 3;                 // most register bits (columns of a block = 2^RB, MCfg)
-constexpr int MKE = 10;                // most paired events (eq block of 2^MKE states in LDS)
+constexpr int MKE = 9;                 // most paired events (eq block of 2^MKE states in LDS)
 
 // static description of one joint problem on the matrix path (host-built, set_cohort)
 struct MDesc {
@@ -135,7 +135,7 @@ constexpr int MTHC = (MAXK * MAXK + 7) / 8 * 8;                  // thc area, pa
 template <typename T>
 constexpr size_t msolve_lds() {
   return (size_t)(2 * (1 << MCfg<T>::RB) * MROWS + MTHC + 2 * (1 << MKE) + (MCfg<T>::KD + 1) * (1 << MCfg<T>::KD) +
-                  MCfg<T>::NML * MROWS) * sizeof(T) + 64 * sizeof(int);
+                  (MCfg<T>::NML + 1) * MROWS) * sizeof(T) + 64 * sizeof(int);
 }
 
 template <int I> struct IC { static constexpr int value = I; };
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
   // times the effects of the minor-class events that already happened; kronvec.py:299-323 / 370-395)
   T* Rmin = se + (1 << MKE);                                  // [kmin][2^kmin]
   T* dminL = Rmin + KD * (1 << KD);                           // [2^kmin] minor-class part of the diagonal
-  T* RLl = dminL + (1 << KD);                                 // [NML][MROWS] rate of the i-th left-over-bit move of a row
-  int* bits = reinterpret_cast<int*>(RLl + NML * MROWS);      // [0..9] tb, [16..23] mlb, [32..55] mnb
+  T* RLl = dminL + (1 << KD);                                 // [NML + 1][MROWS] rate of the i-th left-over-bit move of a row; row NML: zeros
+  int* bits = reinterpret_cast<int*>(RLl + (NML + 1) * MROWS);      // [0..9] tb, [16..23] mlb, [32..55] mnb
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ul[MUPW];                                               // level of unit ui (scalar), -1: none
@@ -257,6 +257,9 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
       Rmin[e] = r;
     }
     for (uint32_t e = tid; e < Vmin; e += MTHREADS) dminL[e] = dmint[e];
+    // rows of zeros: block-bit slots that are not minor-class moves of this patient read their "rate" there
+    for (uint32_t e = ((uint32_t)kmin << kmin) + tid; e < ((uint32_t)(PF + RB) << kmin) && e < (uint32_t)(KD << KD); e += MTHREADS) Rmin[e] = T(0);
+    for (uint32_t e = tid; e < (uint32_t)MROWS; e += MTHREADS) RLl[NML * MROWS + e] = T(0);
     __syncthreads();
     // ---- seed = 0 part: lattice over the paired events (only PT == MT states carry values)
     auto solve_eq = [&]() {
@@ -364,7 +367,6 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
     for (int ui = 0; ui < MUPW; ++ui) voff[ui] = urk[ui] * (uint32_t)sizeof(VecT);
     // ---- moves along the serial bits above the register bits: the thread's own earlier blocks.  PF of them are
     // requested one unit ahead (pj / pv), any more (spaces with more than PF such bits) are fetched on the spot.
-    int pj[PF];
     VecT pv[PF];
     uint32_t prest = 0;
     // rows of a column block are read / written as base (buffer descriptor + scalar block offset) + 32-bit lane offset:
@@ -394,19 +396,23 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
       return (uint32_t)(TR ? B + (1 << jb) : B - (1 << jb));
 #endif
     };
+    // Prefetch slot q holds the neighbour along block bit q, whether the block has that move or not: a move that does
+    // not exist is requested beyond the end of the buffer (the hardware returns zeros without touching memory), so
+    // the step loop has no per-move control flow - on this kernel the scalar unit, not the vector units, is the
+    // scarce resource (profiles/r3: 87 % busy with per-move branches and bit scans).
     auto issue = [&](auto UI, int B) {
       constexpr int ui = decltype(UI)::value;
-      uint32_t nb_ = (TR ? ~(uint32_t)B : (uint32_t)B) & (uint32_t)(NB - 1);
+      const uint32_t nb_ = (TR ? ~(uint32_t)B : (uint32_t)B) & (uint32_t)(NB - 1);
 #pragma unroll
       for (int q = 0; q < PF; ++q) {
-        pj[q] = -1;
-        if (nb_) {
-          pj[q] = __ffs(nb_) - 1;
-          nb_ &= nb_ - 1;
-          pv[q] = ld_row(nbr_block(B, pj[q]), voff[ui]);
-        }
+        const uint32_t nbk = (uint32_t)(TR ? B + (1 << q) : B - (1 << q));
+        const uint32_t so = ((nb_ >> q) & 1u) ? nbk * BLKB : 0x80000000u;
+        Raw r;
+        r.lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[ui], (int)so, 0);
+        r.hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[ui] + 16, (int)so, 0);
+        pv[q] = __builtin_bit_cast(VecT, r);
       }
-      prest = nb_;
+      prest = nb_ >> PF << PF;
     };
     auto slot = [&](auto UI, int step) {
       constexpr int ui = decltype(UI)::value;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
       if (B >= 0) {
         if (Bmin == (TR ? bmask : 0u)) update(UI, sml);
         {
-          auto rate_of = [&](int jb, T (&rr)[NC]) {           // rates of block-bit move jb for the NC columns
+          auto rate_of = [&](int jb, T (&rr)[NC]) {           // rates of block-bit move jb for the NC columns (on-the-spot moves)
             const int sg = jb + RB;
             if (sg < kmin) {
               const T* rp = Rmin + sg * Vmin + (TR ? smin0 : smin0 - (1u << sg));
@@ -439,46 +445,37 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], nv[c], acc[c]);
           };
-          // (one straight-line case per number of prefetched moves; the rate reads of up to four moves in flight together)
-          auto takes = [&](auto NP) {
-            constexpr int np = decltype(NP)::value;
-            constexpr int G = 4;
+          // the PF prefetched slots: rate = minor-class rate of bit q (a row of zeros when bit q is no minor-class bit)
+          // + left-over-bit rate of the row (a row of zeros when it is none); the value is zero when the move does not exist
+          constexpr int G = 4;
 #pragma unroll
-            for (int q0 = 0; q0 < np; q0 += G) {
-              T rr[G * NC];
+          for (int q0 = 0; q0 < PF; q0 += G) {
+            T rr[G * NC], rl[G];
 #pragma unroll
-              for (int g = 0; g < G; ++g) {
-                T r1[NC];
-                if (q0 + g < np) rate_of(pj[q0 + g], r1);
-                else {
+            for (int g = 0; g < G; ++g) {
+              const int q = q0 + g;
+              if (q < PF) {
+                const uint32_t src = TR ? smin0 : (smin0 & ~(1u << (q + RB)));
+                const T* rp = Rmin + (((uint32_t)(q + RB)) << kmin) + src;
+                const int i = q - nbm;
+                const int row = (i >= 0 && i < nml) ? i : NML;
 #pragma unroll
-                  for (int c = 0; c < NC; ++c) r1[c] = T(0);
-                }
+                for (int c = 0; c < NC; ++c) rr[g * NC + c] = rp[c];
+                rl[g] = RLl[row * MROWS + urk[ui]];
+              } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) rr[g * NC + c] = r1[c];
+                for (int c = 0; c < NC; ++c) rr[g * NC + c] = T(0);
+                rl[g] = T(0);
               }
-              pin_all(rr);
-#pragma unroll
-              for (int g = 0; g < G; ++g)
-                if (q0 + g < np) {
-#pragma unroll
-                  for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[g * NC + c], pv[q0 + g][c], acc[c]);
-                }
             }
-          };
-          int np_ = 0;
+            pin_all(rr);
+            pin_all(rl);
 #pragma unroll
-          for (int q = 0; q < PF; ++q) np_ += pj[q] >= 0 ? 1 : 0;
-          switch (np_) {
-            case 1: takes(IC<1>{}); break;
-            case 2: takes(IC<2>{}); break;
-            case 3: takes(IC<3>{}); break;
-            case 4: takes(IC<4>{}); break;
-            case 5: takes(IC<5>{}); break;
-            case 6: takes(IC<6>{}); break;
-            case 7: takes(IC<(PF >= 7 ? 7 : PF)>{}); break;
-            case 8: takes(IC<(PF >= 8 ? 8 : PF)>{}); break;
-            default: break;
+            for (int g = 0; g < G; ++g)
+              if (q0 + g < PF) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[g * NC + c] + rl[g], pv[q0 + g][c], acc[c]);
+              }
           }
           uint32_t rest = prest;
           while (rest) {
@@ -490,7 +487,9 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
         }
       }
       STAMP(0);
+#ifndef MMHN_ABL_NOTAKE
       if (Bn >= 0) issue(IC<un>{}, Bn);
+#endif
       STAMP(1);
       if (B >= 0) {
         const int l = ul[ui];
@@ -607,8 +606,6 @@ __global__ __launch_bounds__(MTHREADS) void k_msolve(const Desc* __restrict__ de
         STAMP(4);
       }
     };
-#pragma unroll
-    for (int q = 0; q < PF; ++q) pj[q] = -1;
     {
       const int B0 = blk(ul[0], 0);
       if (B0 >= 0) issue(IC<0>{}, B0);
