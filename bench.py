@@ -34,7 +34,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")
+
+
+def csrc_sha16():
+    """Fingerprint of the kernel sources: the offline PMC figures are only quoted for the tree they were taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "metmhn_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -52,7 +63,15 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kronvec / stream / small-cohort legs")
     ap.add_argument("--kronvec-batch", type=int, default=64)
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="BASELINE.json configs[]: 2 = n 20, 5 000 patients per GPU (default, weak scaling); 3 = n 20, 50 000 "
+                         "patients over the GPUs (6 250 per GPU at --gpus 8); 4 = n 25, 10 000 patients over the GPUs, fp32")
+    a = ap.parse_args()
+    if a.config == 3:
+        a.n, a.patients, a.dtype = 20, max(1, 50000 // a.gpus), "f64"
+    elif a.config == 4:
+        a.n, a.patients, a.dtype = 25, max(1, 10000 // a.gpus), "f32"
+    return a
 
 
 def host_cores():
@@ -217,7 +236,8 @@ def main():
         dat = np.vstack([synthetic.full_k_cohort(n, a.patients, seed=2000 + n + 7919 * r) for r in range(world)])
         perc_met, unit_rows = 0.5, a.patients
         wl_name = (f"synthetic full-k cohort, n={n} events, {a.patients} paired patients per GPU, 2^{n}-state vectors, "
-                   f"{a.dtype} (BASELINE.json configs[2] per GPU)")
+                   f"{a.dtype} (BASELINE.json configs[{a.config}]{' per GPU' if a.config == 2 else f' over {world} GPUs'}; "
+                   f"value counts evaluations of 5 000 patients)")
     N = n + 1
     params = np.concatenate((np.asarray(lt).flatten(), dp, dm))
     esz = 8 if a.dtype == "f64" else 4
@@ -244,8 +264,12 @@ def main():
         val, grad = step()
     fence()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / a.steps * 1e3]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                       # per-rank times: a slow rank shows up in the line
+        rank_ms = [float(x.item()) / a.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     cnt = eng.counters()
@@ -259,7 +283,13 @@ def main():
             traffic = json.load(open(TRAFFIC_FILE))
         except Exception:
             traffic = {}
-        traffic_ok = a.workload == "full-k" and n == 20 and a.dtype == "f64" and a.patients == 5000
+        tsrc = traffic.get("source", {})
+        if tsrc.get("csrc_sha16") != csrc_sha16():      # PMC passes of another tree: not quoted
+            traffic = {}
+        traffic_source = (f"recorded offline: profiles/r3_traffic.json (git {tsrc.get('git_head', '?')}, csrc {tsrc.get('csrc_sha16', '?')}; "
+                          "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes over this same command; "
+                          "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)")
+        traffic_ok = a.workload == "full-k" and n == 20 and a.dtype == "f64" and a.patients == 5000 and bool(traffic)
         ek = traffic.get("eval_kernels", {}) if traffic_ok else {}
 
         # ---- measured stream bandwidth of this box (next to the nominal 8 TB/s)
@@ -283,8 +313,7 @@ def main():
                  "avg_launch_ms": avg_ms, "alg_bytes_per_launch": per_launch, "alg_bytes": alg_note,
                  "ms_per_step": c["ms"] / a.steps}
             if tr:
-                o["traffic_source"] = ("recorded offline: profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in "
-                                       "separate passes over this same command; 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)")
+                o["traffic_source"] = traffic_source
                 o["traffic_over_alg"] = tr["bytes_per_launch"] / per_launch
                 o["traffic_GBps"] = tr["bytes_per_launch"] / avg_ms / 1e6
             if stream:
@@ -303,7 +332,8 @@ def main():
         out = {
             "metric": "full-cohort log-lik+grad evals/sec at n=20 events; kronvec HBM GB/s",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if a.config == 2 else "strong", "vs_baseline": None,
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "dtype": a.dtype, "data": "synthetic" if a.workload == "full-k" else "LUAD-reduced genotypes (derived fixture), indep() parameters",
             "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval "
@@ -323,10 +353,22 @@ def main():
                                  "note": "4 x live bytes (write pi, q_J; read each once) / 8 TB/s over the measured step"}
             if stream:
                 out["eval_floor"]["frac_of_floor_measured_copy"] = floor / stream["copy_GBps"] / 1e6 / ms_per_step
+            # "report achieved fraction against B_pat anyway and say which solver ran" - B_pat prices one paired
+            # log-lik + gradient with the reference's k+1 Jacobi sweeps per solve (likelihood.py:231-262):
+            # [(k+1)*3 + (k+1)*4 + 4] * 2^k * s  (forward solve, transposed solve, 1/diag build, one gradient pass)
+            if a.workload == "full-k":
+                kk = n
+                b_pat = ((kk + 1) * 3 + (kk + 1) * 4 + 4) * (2.0 ** kk) * esz
+                b_step = b_pat * unit_rows
+                out["eval_floor"]["B_pat_equivalent"] = {
+                    "bytes_per_patient": b_pat, "bytes_per_step": b_step, "equivalent_GBps": b_step / ms_per_step / 1e6,
+                    "frac_of_peak": b_step / ms_per_step / 1e6 / HBM_PEAK_GBPS,
+                    "note": "Jacobi pricing of SURVEY 8(d) over the measured step; solver that ran = substitution "
+                            "(each state computed once), so this is an equivalence figure, not moved bytes"}
         if ek:
             tot = sum(v.get("bytes_per_launch", 0) * v.get("launches_per_step", 1) for v in ek.values())
             out["eval_traffic"] = {"bytes_per_step": tot, "over_floor": tot / (4.0 * live_bytes) if live_bytes else None,
-                                   "source": "recorded offline: profiles/r2_traffic.json"}
+                                   "source": traffic_source}
 
         if not a.no_extras and a.workload == "full-k":
             # ---- metric 2: batched kronvec Q_off p on `kb` resident 2^k vectors (working set > Infinity
@@ -337,17 +379,25 @@ def main():
             tkv = traffic.get("kronvec", {}) if (n == 20 and kb == 64 and a.dtype == "f64") else {}
             kv = {}
             for name, tr, jac, mult in (("kronvec", 0, 0, 2), ("kronvec_T", 1, 0, 2), ("jacobi_step", 0, 1, 4)):
-                ms = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac)
-                alg = mult * V * kb
-                kv[name] = {"ms_per_launch": ms, "alg_GBps": alg / ms / 1e6, "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBPS,
-                            "batch": kb, "alg_bytes_per_launch": alg}
+                # the timed launch = mmhn_kronvec_batched's launch: y = Q_off p into a NaN-filled y, every tile of every
+                # vector (tiles where Q_off has no entries are zeroed inside the launch)
+                ms, live, tot = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac, tiles=True)
+                alg = mult * V * kb                              # read p once, write y once
+                tile_b = V * kb / tot                            # bytes of one tile of one vector
+                # what the launch has to move: read the tiles that carry values, write all of y (jacobi: + lidg, rhs reads)
+                live_b = (live * tile_b + tot * tile_b) if not jac else (3 * live * tile_b + tot * tile_b)
+                kv[name] = {"ms_per_launch": ms, "batch": kb, "tiles_per_launch": tot, "tiles_with_entries": live,
+                            "alg_bytes_per_launch": alg, "alg_GBps": alg / ms / 1e6,
+                            "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBPS,
+                            "live_bytes_per_launch": live_b, "live_GBps": live_b / ms / 1e6,
+                            "frac_of_peak_live": live_b / ms / 1e6 / HBM_PEAK_GBPS}
                 if name in tkv:
                     kv[name]["traffic"] = tkv[name]["bytes_per_launch"]
                     kv[name]["moved_GBps"] = tkv[name]["bytes_per_launch"] / ms / 1e6
                     kv[name]["frac_of_peak_moved"] = tkv[name]["bytes_per_launch"] / ms / 1e6 / HBM_PEAK_GBPS
-                    kv[name]["traffic_source"] = "recorded offline: profiles/r2_traffic.json"
+                    kv[name]["traffic_source"] = traffic_source
                 if stream:
-                    kv[name]["frac_of_measured_copy"] = alg / ms / 1e6 / stream["copy_GBps"]
+                    kv[name]["frac_of_measured_copy_live"] = live_b / ms / 1e6 / stream["copy_GBps"]
             out["kronvec"] = kv
             note("kronvec leg done")
             # ---- small-k regime (BASELINE configs[0]): one LUAD-sized evaluation, launch-bound

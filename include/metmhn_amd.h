@@ -82,7 +82,13 @@ int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log
  * mmhn_x_partial_D_y  <-> likelihood.x_partial_D_y (:204-228) (takes log_d_p, log_d_m in THAT order)
  * mmhn_partial_diag_scal <-> kronvec.partial_diag_scal_p / _m (:605-644, :674-710): (dD/dlog d[i]) * p,
  *                         which: 0 = p, 1 = m; i in [0, n_mut] (n_mut = the seeding entry)
+ * mmhn_kronvec_batched: the same product for `batch` vectors p[b][2^k] of ONE restricted space (what a vmapped
+ *   kronvec.kronvec does; SURVEY 8b "+ _batched"): one launch over every tile of every vector into y[b][2^k].  The
+ *   device output starts as a NaN pattern and is written completely by that launch (tiles where Q_off has no entries
+ *   are zeroed inside it) - it is the launch sequence mmhn_bench_kronvec times.
  */
+int mmhn_kronvec_batched(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch, const double* p,
+                         double* y, int diag, int transpose);
 int mmhn_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
                  double* y, int diag, int transpose);
 int mmhn_kron_diag(mmhn_handle h, const double* log_theta, const int8_t* state, double* out);
@@ -151,8 +157,10 @@ int mmhn_simulate(mmhn_handle h, const double* log_theta, const double* pt_d_ef,
 
 /* ---- measurement -------------------------------------------------------------------
  * mmhn_bench_kronvec: `batch` resident copies of a 2^k vector, `iters` back-to-back
- * launches of the batched Q_off p kernel (or the fused Jacobi step if jacobi != 0) timed
+ * launches of mmhn_kronvec_batched's launch (diag = 0: y = Q_off p into a NaN-filled y, every tile of every vector,
+ * structurally zero tiles zeroed inside the launch) or of the fused Jacobi step if jacobi != 0, timed
  * with HIP events on the engine's stream; returns the average launch duration in ms.
+ * tiles (optional): [0] = tiles per launch where Q_off has entries, [1] = tiles per launch.
  * mmhn_get_counters: cumulative figures since mmhn_reset_counters, per class of dominant kernel (events recorded
  * on the engine's stream around every launch).
  */
@@ -173,7 +181,7 @@ typedef struct {
   int64_t evals;
 } mmhn_counters;
 int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch,
-                       int iters, int transpose, int jacobi, double* ms_per_launch);
+                       int iters, int transpose, int jacobi, double* ms_per_launch, int64_t* tiles);
 /* device-memory bandwidth of this GPU for a plain 16-byte-per-lane stream over arrays of `bytes` each
  * (kind 0: copy, 1: triad a = b + s c), GB/s of the 2 x / 3 x bytes moved: the measured denominator next to the
  * nominal HBM peak */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mmhn_cohort_sums_end": [C.c_void_p, f64p],
     "mmhn_patient_grads": [C.c_void_p, f64p, f64p, f64p, f64p, f64p, f64p, f64p],
     "mmhn_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
+    "mmhn_kronvec_batched": [C.c_void_p, f64p, i8p, C.c_int64, f64p, f64p, C.c_int, C.c_int],
     "mmhn_kron_diag": [C.c_void_p, f64p, i8p, f64p],
     "mmhn_diag_scal": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int],
     "mmhn_obs_states": [C.c_void_p, i8p, C.c_int, i64p, i64p],
@@ -63,7 +64,7 @@ SIGNATURES = {
     "mmhn_comm_init": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "mmhn_comm_destroy": [C.c_void_p],
     "mmhn_bench_stream": [C.c_void_p, C.c_size_t, C.c_int, C.c_int, f64p],
-    "mmhn_bench_kronvec": [C.c_void_p, f64p, i8p, C.c_int64, C.c_int, C.c_int, C.c_int, f64p],
+    "mmhn_bench_kronvec": [C.c_void_p, f64p, i8p, C.c_int64, C.c_int, C.c_int, C.c_int, f64p, i64p],
     "mmhn_simulate": [C.c_void_p, f64p, f64p, f64p, C.c_int64, C.c_uint64, i8p, i8p],
     "mmhn_get_counters": [C.c_void_p, C.POINTER(Counters)],
     "mmhn_reset_counters": [C.c_void_p],

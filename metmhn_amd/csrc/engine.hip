@@ -1244,6 +1244,56 @@ struct Engine : EngineBase {
     if (diag) launch_diag(m.dd.p, m.map.p, m.ntiles, m.a.p, m.b.p, nullptr, KD_ADDQP);
     down(y, m.b.p, V);
   }
+  // ---- batched product (kronvec.py:499-539 applied to `batch` vectors of one restricted space): ONE launch over every
+  // tile of every vector.  Nothing is cleared beforehand: tiles where Q_off has no entries are zeroed by the kernel
+  // itself (k_kv's kind 1), so y may be any buffer - this is the launch sequence mmhn_bench_kronvec times.
+  struct KvBatch {
+    Desc d;
+    long long batch = 0, V = 0;
+    int ntiles = 0, nlive = 0;                    // tiles per launch; those of them where Q_off has entries
+    bool use_kv = false;
+    DevArr<Desc> dd;
+    DevArr<int2> map;
+    DevArr<T> tab, hxt;
+  };
+  void kv_setup(KvBatch& kb, const Desc& d0, long long batch) {
+    REQUIRE(batch >= 1, "batch must be positive");
+    REQUIRE(d0.k <= MAXK, "too many active events");
+    kb.d = d0; kb.batch = batch; kb.V = 1ll << d0.k;
+    std::vector<Desc> ds((size_t)batch, d0);
+    std::vector<int2> mp;
+    for (long long i = 0; i < batch; ++i) { ds[i].off = i * kb.V; ds[i].aoff = 0; ds[i].toff = 0; add_tiles(mp, (int)i, d0.k); }
+    kb.ntiles = (int)mp.size();
+    kb.nlive = 0;
+    for (const int2& m : mp) if (!dead_tile(ds[m.x], (uint32_t)m.y)) ++kb.nlive;
+    kb.dd.alloc(ds.size()); kb.map.alloc(mp.size());
+    HIPCHECK(hipMemcpyAsync(kb.dd.p, ds.data(), ds.size() * sizeof(Desc), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(kb.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+    kb.tab.alloc((size_t)std::max<long long>(table_size(d0), 1));
+    prep(kb.dd.p, 1, kb.tab.p);                    // one table: every vector lives in the same space
+    kb.use_kv = d0.k > TB && kv_version == 2;
+    if (kb.use_kv) {
+      kb.hxt.alloc(mp.size() * (size_t)d0.k);
+      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.ntiles), dim3(64), 0, stream, kb.dd.p, kb.map.p, kb.tab.p, kb.hxt.p, d0.k);
+      HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipStreamSynchronize(stream));
+  }
+  void kv_launch(const KvBatch& kb, bool tr, const T* p, T* y) {
+    if (kb.use_kv) launch_kv(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, kb.tab.p, kb.hxt.p);
+    else launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, nullptr, nullptr, 0, nullptr, 0, kb.tab.p);
+  }
+  void api_kronvec_batched(const Desc& d, long long batch, const double* p, double* y, bool diag, bool tr) {
+    KvBatch kb; kv_setup(kb, d, batch);
+    const size_t tot = (size_t)(batch * kb.V);
+    DevArr<T> a, b;
+    up(a, p, tot);
+    b.alloc(tot);
+    HIPCHECK(hipMemsetAsync(b.p, 0xFF, tot * sizeof(T), stream));   // NaN pattern: every element must be written by the launch
+    kv_launch(kb, tr, a.p, b.p);
+    if (diag) launch_diag(kb.dd.p, kb.map.p, kb.ntiles, a.p, b.p, nullptr, KD_ADDQP);
+    down(y, b.p, tot);
+  }
   void api_diag(const Desc& d, const double* p, double* outp, int what, int pbit = -1) {
     Mini m; mini_setup(m, d);
     const size_t V = (size_t)1 << d.k;
@@ -1376,51 +1426,28 @@ struct Engine : EngineBase {
       ddm[i] = bq >= 0 ? bm[32 + bq] : 0.0;
     }
   }
-  double bench_kronvec(const Desc& d0, long long batch, int iters, bool tr, bool jacobi) {
+  // tiles[0] = tiles where Q_off has entries, tiles[1] = tiles per launch (both over the whole batch)
+  double bench_kronvec(const Desc& d0, long long batch, int iters, bool tr, bool jacobi, long long* tiles) {
     REQUIRE(batch >= 1 && iters >= 1, "batch and iters must be positive");
-    const long long V = 1ll << d0.k;
-    std::vector<Desc> ds((size_t)batch, d0);
-    std::vector<int2> mp;
-    const long long tsz = table_size(d0);
-    for (long long i = 0; i < batch; ++i) { ds[i].off = i * V; ds[i].aoff = 0; ds[i].toff = i * tsz; add_tiles(mp, (int)i, d0.k); }
-    DevArr<Desc> dd; DevArr<int2> dm; DevArr<T> a, b, c, r, tb;
-    dd.alloc(ds.size()); dm.alloc(mp.size());
-    HIPCHECK(hipMemcpy(dd.p, ds.data(), ds.size() * sizeof(Desc), hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(dm.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice));
+    KvBatch kb; kv_setup(kb, d0, batch);
+    const long long V = kb.V;
+    if (tiles) { tiles[0] = kb.nlive; tiles[1] = kb.ntiles; }
+    DevArr<T> a, b, c, r;
     a.alloc((size_t)(batch * V)); b.alloc((size_t)(batch * V));
-    tb.alloc((size_t)(batch * tsz));
-    prep(dd.p, (int)batch, tb.p);
     std::vector<T> host((size_t)V);
     for (long long i = 0; i < V; ++i) host[(size_t)i] = (T)(1.0 / (double)(1 + (i % 97)));
     for (long long i = 0; i < batch; ++i)
       HIPCHECK(hipMemcpy(a.p + i * V, host.data(), (size_t)V * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemsetAsync(b.p, 0xFF, (size_t)(batch * V) * sizeof(T), stream));   // y starts as NaNs: the launch writes all of it
     if (jacobi) {
       c.alloc((size_t)(batch * V)); r.alloc((size_t)(batch * V));
-      launch_diag(dd.p, dm.p, (int)mp.size(), nullptr, c.p, nullptr, KD_LIDG);
+      launch_diag(kb.dd.p, kb.map.p, kb.ntiles, nullptr, c.p, nullptr, KD_LIDG);
       HIPCHECK(hipMemcpyAsync(r.p, a.p, (size_t)(batch * V) * sizeof(T), hipMemcpyDeviceToDevice, stream));
     }
-    // plain products on multi-tile spaces: the structurally zero tiles (seed = 0, no PT == MT state: Q_off and
-    // Q_off^T have no entries there) are neither read nor written - y is cleared once and only the live tiles are
-    // launched, as the engine's solves do
-    DevArr<T> hxt;
-    DevArr<int2> dlive;
-    const bool use_kv = !jacobi && d0.k > TB && kv_version == 2;
-    int nlive = 0;
-    if (use_kv) {
-      std::vector<int2> live;
-      for (const int2& m : mp) if (!dead_tile(ds[m.x], (uint32_t)m.y)) live.push_back(m);
-      nlive = (int)live.size();
-      dlive.alloc(live.size());
-      HIPCHECK(hipMemcpy(dlive.p, live.data(), live.size() * sizeof(int2), hipMemcpyHostToDevice));
-      HIPCHECK(hipMemsetAsync(b.p, 0, (size_t)(batch * V) * sizeof(T), stream));
-      hxt.alloc(live.size() * (size_t)d0.k);
-      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)nlive), dim3(64), 0, stream, dd.p, dlive.p, tb.p, hxt.p, d0.k);
-      HIPCHECK(hipGetLastError());
-    }
+    // the timed launch is exactly the one mmhn_kronvec_batched issues (plain product), or the fused Jacobi step
     auto run = [&]() {
-      if (use_kv) launch_kv(tr, dd.p, dlive.p, nlive, d0.k, a.p, b.p, tb.p, hxt.p);
-      else launch_sweep(tr, dd.p, dm.p, (int)mp.size(), d0.k, a.p, b.p, jacobi ? c.p : nullptr, jacobi ? r.p : nullptr, 0,
-                        nullptr, 0, tb.p);
+      if (jacobi) launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, d0.k, a.p, b.p, c.p, r.p, 0, nullptr, 0, kb.tab.p);
+      else kv_launch(kb, tr, a.p, b.p);
     };
     run(); run();
     hipEvent_t e0, e1;
@@ -1627,6 +1654,17 @@ int mmhn_kronvec(mmhn_handle h, const double* lt, const int8_t* state, const dou
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
   DISPATCH(h, api_kronvec(d, p, y, diag != 0, transpose != 0));
+  API_END
+}
+int mmhn_kronvec_batched(mmhn_handle h, const double* lt, const int8_t* state, int64_t batch, const double* p,
+                         double* y, int diag, int transpose) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(lt && state && p && y, "null pointer");
+  REQUIRE(batch >= 1, "batch must be positive");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, nullptr, nullptr));
+  DISPATCH(h, api_kronvec_batched(d, batch, p, y, diag != 0, transpose != 0));
   API_END
 }
 int mmhn_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, double* out) {
@@ -1858,16 +1896,18 @@ int mmhn_simulate(mmhn_handle h, const double* lt, const double* pt_d_ef, const 
 
 // ---- measurement
 int mmhn_bench_kronvec(mmhn_handle h, const double* lt, const int8_t* state, int64_t batch, int iters,
-                       int transpose, int jacobi, double* ms_per_launch) {
+                       int transpose, int jacobi, double* ms_per_launch, int64_t* tiles) {
   API_BEGIN
   GUARD(h);
   REQUIRE(lt && state && ms_per_launch, "null pointer");
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
+  long long tl[2] = {0, 0};
   if (h->dtype == MMHN_F64)
-    *ms_per_launch = static_cast<Engine<double>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0);
+    *ms_per_launch = static_cast<Engine<double>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0, tl);
   else
-    *ms_per_launch = static_cast<Engine<float>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0);
+    *ms_per_launch = static_cast<Engine<float>*>(h->impl)->bench_kronvec(d, batch, iters, transpose != 0, jacobi != 0, tl);
+  if (tiles) { tiles[0] = tl[0]; tiles[1] = tl[1]; }
   API_END
 }
 int mmhn_bench_stream(mmhn_handle h, size_t bytes, int iters, int kind, double* gbps) {

@@ -61,6 +61,13 @@ class Engine:
         if workspace_bytes:
             _lib.check(self.lib.mmhn_set_workspace_limit(self.h, int(workspace_bytes)))
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mmhn_destroy(self.h)
@@ -138,6 +145,17 @@ class Engine:
         lt, ltp = _f(log_theta); pv, pp = _f(p); st, sp = _s(state)
         y = np.zeros_like(pv)
         _lib.check(self.lib.mmhn_kronvec(self.h, ltp, sp, pp, y.ctypes.data_as(f64p), int(diag), int(transpose)))
+        return y
+
+    def kronvec_batched(self, log_theta, p, state, diag=True, transpose=False):
+        """kronvec for a batch p[b][2^k] of vectors of one restricted space: one launch, y[b][2^k]."""
+        lt, ltp = _f(log_theta); st, sp = _s(state)
+        pv = np.ascontiguousarray(p, dtype=np.float64)
+        if pv.ndim != 2 or pv.shape[1] != 2 ** int(st.sum()):
+            raise ValueError("p must have shape [batch, 2^k]")
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_kronvec_batched(self.h, ltp, sp, int(pv.shape[0]), pv.ctypes.data_as(f64p),
+                                                 y.ctypes.data_as(f64p), int(diag), int(transpose)))
         return y
 
     def kron_diag(self, log_theta, state):
@@ -269,12 +287,15 @@ class Engine:
         return (dat, od) if orders else dat
 
     # ---- measurement
-    def bench_kronvec(self, log_theta, state, batch, iters, transpose=False, jacobi=False):
+    def bench_kronvec(self, log_theta, state, batch, iters, transpose=False, jacobi=False, tiles=False):
+        """ms per launch of mmhn_kronvec_batched's launch (or the fused Jacobi step); tiles=True also returns
+        (tiles with entries of Q_off, tiles per launch)."""
         lt, ltp = _f(log_theta); st, sp = _s(state)
         ms = C.c_double()
+        tl = (C.c_int64 * 2)()
         _lib.check(self.lib.mmhn_bench_kronvec(self.h, ltp, sp, int(batch), int(iters), int(transpose), int(jacobi),
-                                               C.byref(ms)))
-        return ms.value
+                                               C.byref(ms), tl))
+        return (ms.value, int(tl[0]), int(tl[1])) if tiles else ms.value
 
     def bench_stream(self, nbytes=1 << 30, iters=10, kind="copy"):
         """Measured device-memory bandwidth (GB/s) of a plain copy / triad stream on this GPU."""

@@ -858,3 +858,35 @@ def test_matrix_layout_solves_match_cpu_port(monkeypatch):
     for x, y in zip(*res):
         assert np.isfinite(x).all()
         np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_batched_kronvec_at_benchmarked_shape():
+    """mmhn_kronvec_batched = the launch mmhn_bench_kronvec times (k_kv: 256 tiles per vector, 8 tile bits, neighbour
+    pipeline, scalar-unit U rows), at the benchmarked shape n = k = 20 with B = 4 random vectors.  The device output
+    starts as NaNs, so every state of y - including the tiles where Q_off has no entries - must be written by that one
+    launch.  Against ref_kronvec (oracle/metmhn_ref.c: the reference's factor-by-factor passes) to 1e-9, both
+    transposes, diag 0 / 1; the same at k = 16 and k = 14."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    cref.load()
+    rng = np.random.default_rng(77)
+    for n, kk, B in ((20, 20, 4), (16, 16, 3), (20, 14, 2)):
+        lt, _, _ = synthetic.random_params(n, seed=300 + kk)
+        st = synthetic.full_k_cohort(n, 1, k=kk, seed=500 + kk)[0, :2 * n + 1]
+        assert int(st.sum()) == kk
+        p = rng.random((B, 2 ** kk)) + 0.01
+        with Engine(n) as e:
+            for tr in (False, True):
+                for diag in (False, True):
+                    y = e.kronvec_batched(lt, p, st, diag=diag, transpose=tr)
+                    assert np.isfinite(y).all(), f"k={kk} tr={tr} diag={diag}: unwritten states"
+                    for b in range(B if kk < 20 else 2):            # (the CPU passes take seconds at k = 20)
+                        ref = cref.kronvec(lt, p[b], st, diag=diag, transpose=tr)
+                        np.testing.assert_allclose(y[b], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max(),
+                                                   err_msg=f"k={kk} tr={tr} diag={diag} b={b}")
+            # single-vector entry point and the batched one agree
+            np.testing.assert_allclose(e.kronvec(lt, p[0], st, diag=False), e.kronvec_batched(lt, p[:1], st, diag=False)[0],
+                                       rtol=1e-13)
+            ms, live, tot = e.bench_kronvec(lt, st, B, 2, tiles=True)
+            assert ms > 0 and 0 < live <= tot == B * max(1, 2 ** (kk - 12))
