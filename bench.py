@@ -384,8 +384,9 @@ def main():
                 ms, live, tot = eng.bench_kronvec(lt, st, kb, 20, transpose=tr, jacobi=jac, tiles=True)
                 alg = mult * V * kb                              # read p once, write y once
                 tile_b = V * kb / tot                            # bytes of one tile of one vector
-                # what the launch has to move: read the tiles that carry values, write all of y (jacobi: + lidg, rhs reads)
-                live_b = (live * tile_b + tot * tile_b) if not jac else (3 * live * tile_b + tot * tile_b)
+                # what the launch has to move: read the tiles of p that carry values, write all of y (the Jacobi step also
+                # reads 1/diag and the right-hand side of every tile: a tile without entries still gets lidg * rhs)
+                live_b = (live * tile_b + tot * tile_b) if not jac else (live * tile_b + 3 * tot * tile_b)
                 kv[name] = {"ms_per_launch": ms, "batch": kb, "tiles_per_launch": tot, "tiles_with_entries": live,
                             "alg_bytes_per_launch": alg, "alg_GBps": alg / ms / 1e6,
                             "frac_of_peak": alg / ms / 1e6 / HBM_PEAK_GBPS,

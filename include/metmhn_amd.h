@@ -89,6 +89,12 @@ int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log
  */
 int mmhn_kronvec_batched(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch, const double* p,
                          double* y, int diag, int transpose);
+/* one sweep of likelihood.R_i_inv_vec's Jacobi iteration (likelihood.py:253-255), batched as above:
+ * y[b] = lidg * (Q_off p[b] + rhs[b]) (transpose: Q_off^T), lidg = 1 / (D_p + D_m - diag Q); the launch
+ * mmhn_bench_kronvec times with jacobi != 0 */
+int mmhn_jacobi_step_batched(mmhn_handle h, const double* log_theta, const double* log_d_p, const double* log_d_m,
+                             const int8_t* state, int64_t batch, const double* p, const double* rhs, double* y,
+                             int transpose);
 int mmhn_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, const double* p,
                  double* y, int diag, int transpose);
 int mmhn_kron_diag(mmhn_handle h, const double* log_theta, const int8_t* state, double* out);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mmhn_patient_grads": [C.c_void_p, f64p, f64p, f64p, f64p, f64p, f64p, f64p],
     "mmhn_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
     "mmhn_kronvec_batched": [C.c_void_p, f64p, i8p, C.c_int64, f64p, f64p, C.c_int, C.c_int],
+    "mmhn_jacobi_step_batched": [C.c_void_p, f64p, f64p, f64p, i8p, C.c_int64, f64p, f64p, f64p, C.c_int],
     "mmhn_kron_diag": [C.c_void_p, f64p, i8p, f64p],
     "mmhn_diag_scal": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int],
     "mmhn_obs_states": [C.c_void_p, i8p, C.c_int, i64p, i64p],

@@ -396,8 +396,10 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tsolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, true, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv<T, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<T, true>),
@@ -491,11 +493,20 @@ struct Engine : EngineBase {
     if (timed) HIPCHECK(hipEventRecord(e1, stream));
   }
   // plain product on full tiles of multi-tile spaces (k_kv); hxt from k_hx for the same map
-  void launch_kv(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, const T* p, T* y, const T* tab, const T* hxt) {
+  // zmap: see k_kv; lidg / rhs: fused Jacobi step y = lidg * (Q_off p + rhs) over the same tile list
+  void launch_kv(bool tr, const Desc* descs, const int2* map, int ntiles, int maxk, const T* p, T* y, const T* tab, const T* hxt,
+                 const int* zmap = nullptr, const T* lidg = nullptr, const T* rhs = nullptr) {
     if (ntiles == 0) return;
     const size_t lds = DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)maxk * 64 + 32) * sizeof(T);
-    if (tr) hipLaunchKernelGGL((k_kv<T, true, 1>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, ntiles, p, y, tab, hxt, maxk);
-    else hipLaunchKernelGGL((k_kv<T, false, 1>), dim3(ntiles), dim3(KSB), lds, stream, descs, map, ntiles, p, y, tab, hxt, maxk);
+#define KV_ARGS dim3(ntiles), dim3(KSB), lds, stream, descs, map, ntiles, p, y, tab, hxt, maxk, zmap, lidg, rhs
+    if (lidg) {
+      if (tr) hipLaunchKernelGGL((k_kv<T, true, 1, true>), KV_ARGS);
+      else hipLaunchKernelGGL((k_kv<T, false, 1, true>), KV_ARGS);
+    } else {
+      if (tr) hipLaunchKernelGGL((k_kv<T, true, 1, false>), KV_ARGS);
+      else hipLaunchKernelGGL((k_kv<T, false, 1, false>), KV_ARGS);
+    }
+#undef KV_ARGS
     HIPCHECK(hipGetLastError());
   }
   void collect_events() {
@@ -1250,11 +1261,12 @@ struct Engine : EngineBase {
   struct KvBatch {
     Desc d;
     long long batch = 0, V = 0;
-    int ntiles = 0, nlive = 0;                    // tiles per launch; those of them where Q_off has entries
+    int ntiles = 0, nlive = 0;                    // tiles of the batch; those of them where Q_off has entries
     bool use_kv = false;
     DevArr<Desc> dd;
-    DevArr<int2> map;
-    DevArr<T> tab, hxt;
+    DevArr<int2> map, live;                       // every tile; the tiles with entries (what the plain product launches)
+    DevArr<int> zmap;                             // per live tile: the structurally zero tile its workgroup clears, -1: none
+    DevArr<T> tab, hxt, hxl;                      // hxt: tile-bit factors for `map`, hxl: for `live`
   };
   void kv_setup(KvBatch& kb, const Desc& d0, long long batch) {
     REQUIRE(batch >= 1, "batch must be positive");
@@ -1264,8 +1276,29 @@ struct Engine : EngineBase {
     std::vector<int2> mp;
     for (long long i = 0; i < batch; ++i) { ds[i].off = i * kb.V; ds[i].aoff = 0; ds[i].toff = 0; add_tiles(mp, (int)i, d0.k); }
     kb.ntiles = (int)mp.size();
-    kb.nlive = 0;
-    for (const int2& m : mp) if (!dead_tile(ds[m.x], (uint32_t)m.y)) ++kb.nlive;
+    std::vector<int2> lv;
+    std::vector<int> zm;
+    for (const int2& m : mp) {
+      if (dead_tile(ds[m.x], (uint32_t)m.y)) continue;
+      lv.push_back(m);
+      // a seeded tile clears its seed = 0 counterpart when Q_off has no entries there (dead tiles only exist with the
+      // seeding bit above the tile bits, and the counterpart of a dead tile is always live)
+      int z = -1;
+      if (d0.mode == JOINT && d0.seedbit >= TB) {
+        const uint32_t sb = 1u << (d0.seedbit - TB);
+        if (((uint32_t)m.y & sb) && dead_tile(ds[m.x], (uint32_t)m.y & ~sb)) z = (int)((uint32_t)m.y & ~sb);
+      }
+      zm.push_back(z);
+    }
+    kb.nlive = (int)lv.size();
+    {
+      size_t cleared = 0;
+      for (int z : zm) cleared += z >= 0;
+      REQUIRE(cleared + lv.size() == mp.size(), "kronvec: a structurally zero tile has no live counterpart");
+    }
+    kb.live.alloc(lv.size()); kb.zmap.alloc(zm.size());
+    HIPCHECK(hipMemcpyAsync(kb.live.p, lv.data(), lv.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(kb.zmap.p, zm.data(), zm.size() * sizeof(int), hipMemcpyHostToDevice, stream));
     kb.dd.alloc(ds.size()); kb.map.alloc(mp.size());
     HIPCHECK(hipMemcpyAsync(kb.dd.p, ds.data(), ds.size() * sizeof(Desc), hipMemcpyHostToDevice, stream));
     HIPCHECK(hipMemcpyAsync(kb.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
@@ -1274,14 +1307,19 @@ struct Engine : EngineBase {
     kb.use_kv = d0.k > TB && kv_version == 2;
     if (kb.use_kv) {
       kb.hxt.alloc(mp.size() * (size_t)d0.k);
+      kb.hxl.alloc(lv.size() * (size_t)d0.k);
       hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.ntiles), dim3(64), 0, stream, kb.dd.p, kb.map.p, kb.tab.p, kb.hxt.p, d0.k);
+      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.nlive), dim3(64), 0, stream, kb.dd.p, kb.live.p, kb.tab.p, kb.hxl.p, d0.k);
       HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipStreamSynchronize(stream));
   }
-  void kv_launch(const KvBatch& kb, bool tr, const T* p, T* y) {
-    if (kb.use_kv) launch_kv(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, kb.tab.p, kb.hxt.p);
-    else launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, nullptr, nullptr, 0, nullptr, 0, kb.tab.p);
+  // plain product: the live tiles, each seeded one clearing its structurally zero counterpart - all of y is written;
+  // fused Jacobi step (lidg, rhs given): every tile
+  void kv_launch(const KvBatch& kb, bool tr, const T* p, T* y, const T* lidg = nullptr, const T* rhs = nullptr) {
+    if (kb.use_kv && lidg) launch_kv(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, kb.tab.p, kb.hxt.p, nullptr, lidg, rhs);
+    else if (kb.use_kv) launch_kv(tr, kb.dd.p, kb.live.p, kb.nlive, kb.d.k, p, y, kb.tab.p, kb.hxl.p, kb.zmap.p);
+    else launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, lidg, rhs, 0, nullptr, 0, kb.tab.p);
   }
   void api_kronvec_batched(const Desc& d, long long batch, const double* p, double* y, bool diag, bool tr) {
     KvBatch kb; kv_setup(kb, d, batch);
@@ -1292,6 +1330,21 @@ struct Engine : EngineBase {
     HIPCHECK(hipMemsetAsync(b.p, 0xFF, tot * sizeof(T), stream));   // NaN pattern: every element must be written by the launch
     kv_launch(kb, tr, a.p, b.p);
     if (diag) launch_diag(kb.dd.p, kb.map.p, kb.ntiles, a.p, b.p, nullptr, KD_ADDQP);
+    down(y, b.p, tot);
+  }
+  // one fused Jacobi step of R_i_inv_vec (likelihood.py:253-255) for `batch` vectors of one space:
+  // y = lidg * (Q_off p + rhs) (transposed: Q_off^T), lidg = 1 / (D_p + D_m - diag Q) - the launch mmhn_bench_kronvec
+  // times with jacobi != 0
+  void api_jacobi_step_batched(const Desc& d, long long batch, const double* p, const double* rhs, double* y, bool tr) {
+    KvBatch kb; kv_setup(kb, d, batch);
+    const size_t tot = (size_t)(batch * kb.V);
+    DevArr<T> a, b, c, r;
+    up(a, p, tot);
+    up(r, rhs, tot);
+    b.alloc(tot); c.alloc(tot);
+    launch_diag(kb.dd.p, kb.map.p, kb.ntiles, nullptr, c.p, nullptr, KD_LIDG);
+    HIPCHECK(hipMemsetAsync(b.p, 0xFF, tot * sizeof(T), stream));
+    kv_launch(kb, tr, a.p, b.p, c.p, r.p);
     down(y, b.p, tot);
   }
   void api_diag(const Desc& d, const double* p, double* outp, int what, int pbit = -1) {
@@ -1446,7 +1499,8 @@ struct Engine : EngineBase {
     }
     // the timed launch is exactly the one mmhn_kronvec_batched issues (plain product), or the fused Jacobi step
     auto run = [&]() {
-      if (jacobi) launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, d0.k, a.p, b.p, c.p, r.p, 0, nullptr, 0, kb.tab.p);
+      if (jacobi && kv_version != 2) launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, d0.k, a.p, b.p, c.p, r.p, 0, nullptr, 0, kb.tab.p);
+      else if (jacobi) kv_launch(kb, tr, a.p, b.p, c.p, r.p);
       else kv_launch(kb, tr, a.p, b.p);
     };
     run(); run();
@@ -1665,6 +1719,17 @@ int mmhn_kronvec_batched(mmhn_handle h, const double* lt, const int8_t* state, i
   const Desc d = JOINT_DESC(state);
   DISPATCH(h, build_params(lt, nullptr, nullptr));
   DISPATCH(h, api_kronvec_batched(d, batch, p, y, diag != 0, transpose != 0));
+  API_END
+}
+int mmhn_jacobi_step_batched(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, const int8_t* state,
+                             int64_t batch, const double* p, const double* rhs, double* y, int transpose) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(lt && ldp && ldm && state && p && rhs && y, "null pointer");
+  REQUIRE(batch >= 1, "batch must be positive");
+  const Desc d = JOINT_DESC(state);
+  DISPATCH(h, build_params(lt, ldp, ldm));
+  DISPATCH(h, api_jacobi_step_batched(d, batch, p, rhs, y, transpose != 0));
   API_END
 }
 int mmhn_kron_diag(mmhn_handle h, const double* lt, const int8_t* state, double* out) {

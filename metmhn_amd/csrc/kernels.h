@@ -485,10 +485,17 @@ __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const
 #ifndef MMHN_KV_WPS
 #define MMHN_KV_WPS 4          // waves per SIMD k_kv's registers are sized for (4: two 512-thread workgroups per CU, 128 VGPRs)
 #endif
-template <typename T, bool TR, int TPW>
+// zmap (optional): zmap[i] = a tile of the same vector in which Q_off has no entries (a seed = 0 tile without PT == MT
+//   states, -1: none) that the workgroup of list entry i clears on its way - the product then fills ALL of y with a
+//   launch over the live tiles only (no memset, no workgroups that do nothing but store zeros).
+// JAC: fused Jacobi step y = lidg * (Q_off p + rhs)  (likelihood.py:253-255); every tile is launched (a tile without
+//   entries still gets lidg * rhs).
+template <typename T, bool TR, int TPW, bool JAC>
 __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict__ descs, const int2* __restrict__ map, int ntiles,
                                                          const T* __restrict__ p, T* __restrict__ y,
-                                                         const T* __restrict__ tab, const T* __restrict__ hxt, int maxk) {
+                                                         const T* __restrict__ tab, const T* __restrict__ hxt, int maxk,
+                                                         const int* __restrict__ zmap, const T* __restrict__ lidg,
+                                                         const T* __restrict__ rhs) {
   extern __shared__ __align__(16) unsigned char smem[];
   Desc& dsh = *reinterpret_cast<Desc*>(smem);              // only staged for the generic path
   T* tile = reinterpret_cast<T*>(smem + DESC_PAD);
@@ -549,11 +556,26 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
 #pragma unroll
       for (int j = 0; j < NJ; ++j) vnext[j] = (p + basen + (Hn << t))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
     }
+    if (!JAC && zmap) {                                        // the structurally zero tile this workgroup clears
+      const int zt = sgpr(zmap[blk]);
+      if (zt >= 0) {
+        for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
+          T* dst = y + base + ((uint32_t)zt << t) + e;
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(zero4) : "memory");
+        }
+      }
+    }
     if (kind == 1) {                                           // Q_off has no entries in this tile
       for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
         T* dst = y + base + xhi + e;
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(zero4) : "memory");
+        if (JAC) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) dst[u] = lidg[base + xhi + e + u] * rhs[base + xhi + e + u];
+        } else {
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(zero4) : "memory");
+        }
       }
       continue;
     }
@@ -577,6 +599,15 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
     T acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0;
+    T jl[JAC ? NJ : 1], jr[JAC ? NJ : 1];                    // fused Jacobi step: this thread's 1/diag and rhs, in flight during the terms
+    if (JAC) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const long long xi = base + xhi + ((((uint32_t)(wave * NJ + j)) << 6) | (uint32_t)lane);
+        jl[j] = lidg[xi];
+        jr[j] = rhs[xi];
+      }
+    }
     if (kind == 0) {
       // Every term is  acc[j] += L_b[lane] * hx[b] * U_b[row] * neighbour.  The wave's NJ rows are consecutive and
       // wave-uniform, so U_b[row] comes through the scalar unit from the table in global memory (one 64-byte scalar
@@ -721,6 +752,10 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
     }
     // y is not read again by this launch: it leaves through LDS as 16-byte write-through stores that do not stay in
     // the XCD's L2, which keeps the p tiles that later tiles read as neighbours
+    if (JAC) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] = jl[j] * (acc[j] + jr[j]);
+    }
 #if MMHN_KV_DIRECT
     // (variant: 8-byte write-through stores straight from the accumulators, no trip through LDS)
 #pragma unroll

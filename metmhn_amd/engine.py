@@ -158,6 +158,18 @@ class Engine:
                                                  y.ctypes.data_as(f64p), int(diag), int(transpose)))
         return y
 
+    def jacobi_step_batched(self, log_theta, log_d_p, log_d_m, p, rhs, state, transpose=False):
+        """One sweep of R_i_inv_vec's iteration for a batch: lidg * (Q_off p + rhs), shapes [batch, 2^k]."""
+        lt, ltp = _f(log_theta); a, ap = _f(log_d_p); b, bp = _f(log_d_m); st, sp = _s(state)
+        pv = np.ascontiguousarray(p, dtype=np.float64)
+        rv = np.ascontiguousarray(rhs, dtype=np.float64)
+        if pv.ndim != 2 or pv.shape != rv.shape or pv.shape[1] != 2 ** int(st.sum()):
+            raise ValueError("p and rhs must have shape [batch, 2^k]")
+        y = np.zeros_like(pv)
+        _lib.check(self.lib.mmhn_jacobi_step_batched(self.h, ltp, ap, bp, sp, int(pv.shape[0]), pv.ctypes.data_as(f64p),
+                                                     rv.ctypes.data_as(f64p), y.ctypes.data_as(f64p), int(transpose)))
+        return y
+
     def kron_diag(self, log_theta, state):
         lt, ltp = _f(log_theta); st, sp = _s(state)
         y = np.zeros(2 ** int(st.sum()))

@@ -890,3 +890,28 @@ def test_batched_kronvec_at_benchmarked_shape():
                                        rtol=1e-13)
             ms, live, tot = e.bench_kronvec(lt, st, B, 2, tiles=True)
             assert ms > 0 and 0 < live <= tot == B * max(1, 2 ** (kk - 12))
+
+
+@pytest.mark.gpu
+def test_fused_jacobi_step_at_benchmarked_shape():
+    """The fused Jacobi step mmhn_bench_kronvec times (k_kv with the 1/diag and right-hand-side epilogue, every tile
+    launched, y starting as NaNs) against lidg * (ref_kronvec(p, diag=False) + rhs) with the oracle's diagonal,
+    n = k = 20 and k = 14, both transposes (likelihood.py:249-255)."""
+    from oracle import cref, metmhn_oracle as O
+    from metmhn_amd import Engine, synthetic
+    cref.load()
+    rng = np.random.default_rng(78)
+    for n, kk, B in ((20, 20, 2), (20, 14, 2)):
+        lt, dp, dm = synthetic.random_params(n, seed=310 + kk)
+        st = synthetic.full_k_cohort(n, 1, k=kk, seed=510 + kk)[0, :2 * n + 1]
+        p = rng.random((B, 2 ** kk)) + 0.01
+        rhs = rng.random((B, 2 ** kk))
+        ones = np.ones(2 ** kk)
+        lidg = 1.0 / (O.diag_scal_p(dp, st, ones) + O.diag_scal_m(dm, st, ones) - O.kron_diag(lt, st, kk))
+        with Engine(n) as e:
+            for tr in (False, True):
+                y = e.jacobi_step_batched(lt, dp, dm, p, rhs, st, transpose=tr)
+                assert np.isfinite(y).all()
+                for b in range(B):
+                    ref = lidg * (cref.kronvec(lt, p[b], st, diag=False, transpose=tr) + rhs[b])
+                    np.testing.assert_allclose(y[b], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max(), err_msg=f"k={kk} tr={tr}")
