@@ -66,6 +66,13 @@ int mmhn_cohort_sums(mmhn_handle h, const double* log_theta, const double* log_d
 int mmhn_cohort_sums_begin(mmhn_handle h, const double* log_theta, const double* log_d_p,
                            const double* log_d_m, int with_grad);
 int mmhn_cohort_sums_end(mmhn_handle h, double* sums);
+/* The same evaluation with the EM / NM weighting of regularized_optimization.py:256-266 applied on the device:
+ * wsums[1 + N*N + 2 N] = [w s_EM + s_NM, w G_EM + G_NM, w p_EM + p_NM, w m_EM]; the caller divides by
+ * n_full = w n_em + n_nm.  w needs the GLOBAL counts only (known to every rank once the cohort is set), so with a
+ * communicator attached the all-reduce carries 1 + N^2 + 2 N doubles (484 at n = 20). */
+int mmhn_cohort_wsums_begin(mmhn_handle h, const double* log_theta, const double* log_d_p,
+                            const double* log_d_m, int with_grad, double w);
+int mmhn_cohort_wsums_end(mmhn_handle h, double* wsums);
 /* per-patient results of the current cohort (tests): lp[n_pat], and if non-NULL
  * d_theta[n_pat][N*N], d_dp[n_pat][N], d_dm[n_pat][N]  (ssr._g_coupled_*, _grad_*_obs) */
 int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log_d_p,

@@ -271,6 +271,17 @@ __global__ void k_pack_sums(const double* __restrict__ sums, int N, double n_em,
   }
 }
 
+// sums[2][stride] -> the pre-combined buffer of mmhn_cohort_wsums: [w s_EM + s_NM, w G_EM + G_NM, w p_EM + p_NM, w m_EM]
+// (regularized_optimization.py:256-266 without the division by n_full): 1 + N^2 + 2 N doubles, the all-reduce
+// payload of SURVEY 8e - the weight w only needs the GLOBAL counts, which every rank knows when the cohort is set
+__global__ void k_pack_wsums(const double* __restrict__ sums, int N, double w, double* __restrict__ o) {
+  const int st = 1 + N * N + 2 * N, NN = N * N;
+  const double* em = sums;
+  const double* nm = sums + st;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < st; e += gridDim.x * blockDim.x)
+    o[e] = e < 1 + NN + N ? w * em[e] + nm[e] : w * em[e];          // (d_d_m has no NM part, :266)
+}
+
 template <typename T>
 struct Engine : EngineBase {
   int n = 0, N = 0;
@@ -1146,25 +1157,32 @@ struct Engine : EngineBase {
   // regularized_optimization.py:296) runs next to the GPU; end: wait and copy out.
   bool sums_pending = false;
   std::chrono::steady_clock::time_point sums_t0, sums_issued;
-  void cohort_sums_begin(const double* lt, const double* ldp, const double* ldm, bool grad) {
+  // w_combined (optional): pack w * EM + NM on the device (k_pack_wsums) - 1 + N^2 + 2N doubles travel instead of
+  // 4 + 2 N^2 + 3 N
+  int sums_len = 0;                                           // doubles of the pending result
+  void cohort_sums_begin(const double* lt, const double* ldp, const double* ldm, bool grad, const double* w_combined = nullptr) {
     REQUIRE(!sums_pending, "mmhn_cohort_sums_begin: the previous evaluation has not been collected");
     sums_t0 = std::chrono::steady_clock::now();
-    const int total = 4 + 2 * N * N + 3 * N;
-    abi_sums.alloc(total);
-    if (!h_abi) HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)total * sizeof(double), hipHostMallocDefault));
+    const int full = 4 + 2 * N * N + 3 * N;
+    const int total = w_combined ? stride() : full;
+    abi_sums.alloc(full);
+    if (!h_abi) HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)full * sizeof(double), hipHostMallocDefault));
     evaluate(lt, ldp, ldm, grad, nullptr, nullptr);
-    hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, abi_sums.p);
+    if (w_combined) hipLaunchKernelGGL(k_pack_wsums, dim3(2), dim3(256), 0, stream, sums.p, N, *w_combined, abi_sums.p);
+    else hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, abi_sums.p);
     HIPCHECK(hipGetLastError());
     if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
     HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
     sums_issued = std::chrono::steady_clock::now();
     sums_pending = true;
+    sums_len = total;
   }
-  void cohort_sums_end(double* o) {
+  void cohort_sums_end(double* o, int expect_len) {
     REQUIRE(sums_pending, "mmhn_cohort_sums_end without mmhn_cohort_sums_begin");
+    REQUIRE(expect_len == sums_len, "mmhn_cohort_sums_end / mmhn_cohort_wsums_end does not match the _begin call");
     sums_pending = false;
     HIPCHECK(hipStreamSynchronize(stream));
-    std::memcpy(o, h_abi, (size_t)(4 + 2 * N * N + 3 * N) * sizeof(double));
+    std::memcpy(o, h_abi, (size_t)sums_len * sizeof(double));
     static const bool trace_host = std::getenv("MMHN_TRACE_HOST") != nullptr;   // diagnostic: host time to issue vs total
     if (trace_host)
       std::fprintf(stderr, "[mmhn] evaluation issued after %.1f us, complete after %.1f us\n",
@@ -1176,7 +1194,7 @@ struct Engine : EngineBase {
   // 75 us instead of 535 us, but the graph takes 660 us to execute against 550 us for the eager launches - dropped.)
   void cohort_sums(const double* lt, const double* ldp, const double* ldm, bool grad, double* o) {
     cohort_sums_begin(lt, ldp, ldm, grad);
-    cohort_sums_end(o);
+    cohort_sums_end(o, 4 + 2 * N * N + 3 * N);
   }
 
   void comm_init(const ncclUniqueId& id, int rank, int nranks) {
@@ -1640,7 +1658,24 @@ int mmhn_cohort_sums_end(mmhn_handle h, double* sums) {
   API_BEGIN
   GUARD(h);
   REQUIRE(sums, "null pointer");
-  DISPATCH(h, cohort_sums_end(sums));
+  DISPATCH(h, cohort_sums_end(sums, 4 + 2 * (h->n + 1) * (h->n + 1) + 3 * (h->n + 1)));
+  API_END
+}
+
+int mmhn_cohort_wsums_begin(mmhn_handle h, const double* lt, const double* ldp, const double* ldm, int with_grad, double w) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(lt && ldp && ldm, "null pointer");
+  REQUIRE(w == w, "w must be a number");
+  DISPATCH(h, cohort_sums_begin(lt, ldp, ldm, with_grad != 0, &w));
+  API_END
+}
+
+int mmhn_cohort_wsums_end(mmhn_handle h, double* wsums) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(wsums, "null pointer");
+  DISPATCH(h, cohort_sums_end(wsums, 1 + (h->n + 1) * (h->n + 1) + 2 * (h->n + 1)));
   API_END
 }
 

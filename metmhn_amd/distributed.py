@@ -62,6 +62,42 @@ def allreduce_sums(sums: np.ndarray, group=None) -> np.ndarray:
     return t.numpy()
 
 
+def allreduce_sums_fixed_order(sums: np.ndarray, group=None) -> np.ndarray:
+    """MMHN_REDUCE=host_fixed_order: every rank gets every rank's partial buffer and adds them up in rank order on
+    the host - the same association on every rank and in every run (reproducible across runs of one GPU
+    count; the in-library RCCL all-reduce leaves the association to the library)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums
+    t = torch.from_numpy(np.ascontiguousarray(sums, dtype=np.float64))
+    on_gpu = dist.get_backend(group) == "nccl"
+    if on_gpu:
+        t = t.cuda()
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t, group=group)
+    out = np.zeros_like(np.asarray(sums, dtype=np.float64))
+    for part in parts:                                        # rank 0 first, always
+        out = out + part.cpu().numpy()
+    return out
+
+
+def em_weight(n_em: float, n_pat: float, perc_met: float):
+    """(w, n_full) of regularized_optimization.py:121-128 from the GLOBAL counts."""
+    n_nm = n_pat - n_em
+    w = perc_met * n_nm / ((1 - perc_met) * n_em) if n_em * n_nm != 0 else 1.0
+    return w, w * n_em + n_nm
+
+
+def split_wsums(ws: np.ndarray, N: int, n_full: float):
+    """(score, d_theta, d_dp, d_dm) from the pre-combined buffer of mmhn_cohort_wsums."""
+    o = 1
+    g = ws[o:o + N * N].reshape(N, N); o += N * N
+    p = ws[o:o + N]; o += N
+    m = ws[o:o + N]
+    return ws[0] / n_full, g / n_full, p / n_full, m / n_full
+
+
 def combine_sums(sums: np.ndarray, N: int, perc_met: float):
     """(score, d_theta, d_dp, d_dm) from the buffer of mmhn_cohort_sums
     (regularized_optimization.py:256-266)."""

@@ -128,6 +128,16 @@ class Engine:
         _lib.check(self.lib.mmhn_cohort_sums_end(self.h, sums.ctypes.data_as(f64p)))
         return sums
 
+    def cohort_wsums_begin(self, log_theta, log_d_p, log_d_m, w, with_grad=True):
+        """Like cohort_sums_begin with the EM / NM weighting applied on the device (mmhn_cohort_wsums_begin)."""
+        keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        _lib.check(self.lib.mmhn_cohort_wsums_begin(self.h, a, b, c, int(bool(with_grad)), float(w)))
+
+    def cohort_wsums_end(self):
+        ws = np.zeros(1 + self.N * self.N + 2 * self.N)
+        _lib.check(self.lib.mmhn_cohort_wsums_end(self.h, ws.ctypes.data_as(f64p)))
+        return ws
+
     def patient_grads(self, log_theta, log_d_p, log_d_m, with_grad=True):
         keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
         P, N = self.n_pat, self.N

@@ -33,7 +33,8 @@ def configure(device: int | None = None, dtype: str = "f64", shard: bool = True)
 
 def invalidate(dat=None):
     """Drop the cached device cohort of `dat` (all of them if None).  The cache recognises an array by identity
-    (object, buffer address, shape), not by content: call this after changing a cohort array IN PLACE."""
+    (object, buffer address, shape) plus a CRC of 64 sampled rows (`_sample_crc`): in-place edits that touch the
+    sampled rows are noticed and re-uploaded, for anything finer call this after changing a cohort array IN PLACE."""
     for key in list(_CACHE):
         if dat is None or key[0] == id(dat):
             _CACHE.pop(key)[0].close()
@@ -52,24 +53,62 @@ def _rank_world():
 def _join_comm(eng: Engine, rank: int, world: int) -> bool:
     """Attach the engine to an RCCL communicator over the ranks of the torch.distributed job (backend nccl): the
     id travels through torch's object broadcast, the all-reduce itself then runs inside mmhn_cohort_sums on the
-    engine's stream.  False -> the caller keeps the host-staged torch all-reduce (gloo / CPU tests)."""
+    engine's stream.  False -> the caller keeps the host-staged torch all-reduce (gloo / CPU tests).
+
+    The decision is COLLECTIVE: rank 0 always broadcasts (a failure sentinel if it could not make an id), every rank
+    reports whether its mmhn_comm_init succeeded, and the device communicator is used only if all did - otherwise
+    every rank destroys its half and all of them use torch's collective (no rank is ever left alone in one of the two).
+    MMHN_COMM_TIMEOUT (seconds, default 180): a rank whose ncclCommInitRank does not return fails instead of hanging."""
     import os
+    import threading
+    import torch
     import torch.distributed as dist
     from .engine import unique_id
     if world > 1 and dist.get_backend() != "nccl":
         return False
-    try:
-        box = [unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0)
-        eng.comm_init(box[0], rank, world)
+    strict = os.environ.get("MMHN_STRICT_COMM") == "1"
+    err = None
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = unique_id()
+        except Exception as exc:
+            err = exc
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)                # always entered by every rank
+    ok = box[0] is not None
+    if ok:
+        res = {}
+
+        def _init():
+            try:
+                eng.comm_init(box[0], rank, world)
+                res["ok"] = True
+            except Exception as exc:                          # noqa: BLE001
+                res["err"] = exc
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("MMHN_COMM_TIMEOUT", "180")))
+        if th.is_alive():
+            raise TimeoutError("metmhn_amd: ncclCommInitRank did not return within MMHN_COMM_TIMEOUT - a rank is missing")
+        ok = bool(res.get("ok"))
+        err = res.get("err", err)
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_ok = bool(int(flag.item()))
+    else:
+        all_ok = ok
+    if all_ok:
         return True
-    except Exception as exc:                                  # RCCL not loadable: keep torch's collective
-        if os.environ.get("MMHN_STRICT_COMM") == "1":
-            raise
-        import warnings
-        warnings.warn(f"metmhn_amd: in-library RCCL communicator unavailable ({exc}); using torch.distributed")
-        return False
+    if ok:
+        eng.comm_destroy()                                    # some other rank failed: nobody uses the device communicator
+    if strict:
+        raise RuntimeError(f"metmhn_amd: in-library RCCL communicator unavailable on some rank ({err})")
+    import warnings
+    warnings.warn(f"metmhn_amd: in-library RCCL communicator unavailable ({err}); using torch.distributed")
+    return False
 
 
 def _cache_key(dat, rank, world):
@@ -78,6 +117,17 @@ def _cache_key(dat, rank, world):
         return (id(dat), dat.__array_interface__["data"][0], dat.shape, dat.dtype.str, rank, world, _OPTIONS["dtype"])
     arr = np.ascontiguousarray(np.asarray(dat).astype(np.int8))          # lists, foreign array types: by content
     return (None, zlib.crc32(arr.tobytes()), arr.shape, "i1", rank, world, _OPTIONS["dtype"])
+
+
+def _sample_crc(dat: np.ndarray) -> int:
+    """Guard of the identity-keyed cache against in-place edits: CRC of up to 64 evenly spaced rows (a few KB, ~2 us
+    per call - the reference is a pure function of `dat`, a full pass per evaluation would cost more than a LUAD-sized
+    evaluation itself).  Catches relabelled / masked / refilled cohorts; a single edited row between the samples still
+    needs invalidate()."""
+    if dat.shape[0] <= 64:
+        return zlib.crc32(np.ascontiguousarray(dat).tobytes())
+    idx = np.linspace(0, dat.shape[0] - 1, 64).astype(np.int64)
+    return zlib.crc32(np.ascontiguousarray(dat[idx]).tobytes())
 
 
 def _engine_for(dat) -> Engine:
@@ -89,7 +139,10 @@ def _engine_for(dat) -> Engine:
     key = _cache_key(dat, rank, world)
     hit = _CACHE.get(key)
     if hit is not None and (hit[1] is None or hit[1]() is dat):
-        return hit[0]
+        if not isinstance(dat, np.ndarray) or hit[0]._sample_crc == _sample_crc(dat):
+            return hit[0]
+        _CACHE.pop(key)[0].close()                            # same array object, edited in place: lay it out again
+        hit = None
     if hit is not None:                                       # the id was recycled for another array
         _CACHE.pop(key)[0].close()
     for k2 in [k2 for k2, (e2, r2) in _CACHE.items() if r2 is not None and r2() is None]:
@@ -101,9 +154,12 @@ def _engine_for(dat) -> Engine:
     eng = Engine(n_mut, device=_OPTIONS["device"], dtype=_OPTIONS["dtype"])
     rows = arr if world == 1 else arr[_dist.shard_rows(arr, world)[rank]]
     eng.set_cohort(rows)
+    # global EM / NM counts (every rank holds the whole `dat`): the weight of :121-128 is known without communication
+    eng._global_counts = (float(arr[:, -3].sum()), float(arr.shape[0]))
     # MMHN_FORCE_ALLREDUCE=1: run the collective even with one rank (exercises the RCCL path on a 1-GPU box)
+    eng._sample_crc = _sample_crc(dat) if isinstance(dat, np.ndarray) else None
     eng._sharded = world > 1 or os.environ.get("MMHN_FORCE_ALLREDUCE") == "1"
-    eng._device_comm = eng._sharded and _join_comm(eng, rank, world)
+    eng._device_comm = eng._sharded and _reduce_mode() != "host_fixed_order" and _join_comm(eng, rank, world)
     ref = None
     if isinstance(dat, np.ndarray):
         try:
@@ -112,6 +168,11 @@ def _engine_for(dat) -> Engine:
             ref = None
     _CACHE[key] = (eng, ref)
     return eng
+
+
+def _reduce_mode():
+    import os
+    return os.environ.get("MMHN_REDUCE", "")
 
 
 def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool, meanwhile: Callable = None):
@@ -125,8 +186,25 @@ def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool, meanwhile: 
     finally:
         sums = eng.cohort_sums_end()
     if eng._sharded and not eng._device_comm:
-        sums = _dist.allreduce_sums(sums)
+        sums = _dist.allreduce_sums_fixed_order(sums) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(sums)
     return sums, aside
+
+
+def _result(eng: Engine, log_theta, log_d_p, log_d_m, perc_met: float, with_grad: bool, meanwhile: Callable = None):
+    """((score, d_theta, d_dp, d_dm), meanwhile's result).  Sharded engines pre-combine EM and NM on the device
+    (the weight only needs the global counts): 1 + N^2 + 2N doubles cross the ranks instead of 4 + 2 N^2 + 3 N."""
+    if not eng._sharded:
+        sums, aside = _sums(eng, log_theta, log_d_p, log_d_m, with_grad, meanwhile)
+        return _dist.combine_sums(sums, eng.N, perc_met), aside
+    w, n_full = _dist.em_weight(*eng._global_counts, perc_met)
+    eng.cohort_wsums_begin(log_theta, log_d_p, log_d_m, w, with_grad=with_grad)
+    try:
+        aside = meanwhile() if meanwhile is not None else None
+    finally:
+        ws = eng.cohort_wsums_end()
+    if not eng._device_comm:
+        ws = _dist.allreduce_sums_fixed_order(ws) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(ws)
+    return _dist.split_wsums(ws, eng.N, n_full), aside
 
 
 # ---- penalties (host NumPy, as in the reference; regularized_optimization.py:11-52) ----
@@ -173,13 +251,13 @@ def symmetric_penal(params, n_total: int, eps=1e-05):
 def score(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """Log-likelihood of the dataset (regularized_optimization.py:55-130)."""
     eng = _engine_for(dat)
-    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, False)[0], eng.N, perc_met)[0]
+    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, False)[0][0]
 
 
 def score_and_grad(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """(score, d_theta, d_d_p, d_d_m)  (regularized_optimization.py:163-267)."""
     eng = _engine_for(dat)
-    return _dist.combine_sums(_sums(eng, log_theta, log_d_p, log_d_m, True)[0], eng.N, perc_met)
+    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, True)[0]
 
 
 def _unpack(params, n_total):
@@ -193,9 +271,8 @@ def score_reg(params, dat, perc_met: float, penal: Callable, w_penal: float):
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
     eng = _engine_for(dat)
-    sums, (pen, _) = _sums(eng, th, dp, dm, False, meanwhile=lambda: penal(params, n_total))    # penalty next to the GPU
-    sc = _dist.combine_sums(sums, eng.N, perc_met)[0]
-    return np.array(-sc + w_penal * pen)
+    res, (pen, _) = _result(eng, th, dp, dm, perc_met, False, meanwhile=lambda: penal(params, n_total))    # penalty next to the GPU
+    return np.array(-res[0] + w_penal * pen)
 
 
 def score_and_grad_reg(params, dat, perc_met: float, penal: Callable, w_penal: float):
@@ -203,8 +280,7 @@ def score_and_grad_reg(params, dat, perc_met: float, penal: Callable, w_penal: f
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
     eng = _engine_for(dat)
-    sums, (pen, pen_) = _sums(eng, th, dp, dm, True, meanwhile=lambda: penal(params, n_total))  # penalty next to the GPU
-    sc, d_th, d_d_p, d_d_m = _dist.combine_sums(sums, eng.N, perc_met)
+    (sc, d_th, d_d_p, d_d_m), (pen, pen_) = _result(eng, th, dp, dm, perc_met, True, meanwhile=lambda: penal(params, n_total))  # penalty next to the GPU
     grad_vec = np.concatenate((d_th.flatten(), d_d_p, d_d_m))
     return np.array(-sc + w_penal * pen), -grad_vec + w_penal * pen_
 

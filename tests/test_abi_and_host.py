@@ -136,6 +136,72 @@ def test_two_rank_gloo_allreduce_reproduces_full_cohort(golden):
     np.testing.assert_allclose(res[3], g["c1_d_dm"], rtol=1e-10, atol=1e-13)
 
 
+def _worker_wsums(rank, world, port, q):
+    """Pre-combined payload (1 + N^2 + 2N doubles, weight from the GLOBAL counts) through the fixed-order host reduce."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metmhn_amd import distributed as D
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cohorts.npz"))
+    lt, dp, dm, dat = g["c1_log_theta"], g["c1_log_d_p"], g["c1_log_d_m"], g["c1_dat"]
+    N = lt.shape[0]
+    rows = D.shard_rows(dat, world)[rank]
+    s = _oracle_sums(lt, dp, dm, dat[rows])               # this rank's shard, layout of mmhn_cohort_sums
+    w, n_full = D.em_weight(float(dat[:, -3].sum()), float(dat.shape[0]), float(g["c1_perc_met"]))
+    em_s, nm_s = s[0], s[1]
+    o = 4
+    g_em = s[o:o + N * N]; o += N * N
+    g_nm = s[o:o + N * N]; o += N * N
+    p_em = s[o:o + N]; o += N
+    p_nm = s[o:o + N]; o += N
+    m_em = s[o:o + N]
+    ws = np.concatenate(([w * em_s + nm_s], w * g_em + g_nm, w * p_em + p_nm, w * m_em))    # what k_pack_wsums writes
+    a = D.allreduce_sums_fixed_order(ws)
+    b = D.allreduce_sums_fixed_order(ws)
+    c = D.allreduce_sums(ws)
+    assert np.array_equal(a, b)                            # same association every time
+    np.testing.assert_allclose(a, c, rtol=1e-14)
+    res = D.split_wsums(a, N, n_full)
+    if rank == 0:
+        q.put([np.asarray(r) for r in res] + [np.asarray(len(ws))])
+    dist.destroy_process_group()
+
+
+def test_two_rank_precombined_payload_fixed_order(golden):
+    """the all-reduce payload pre-combined with the global EM / NM weight (1 + N^2 + 2N doubles) and the
+    MMHN_REDUCE=host_fixed_order reduction (every partial to every rank, summed in rank order) reproduce the
+    single-process result; two reductions of the same partials are bit-identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_wsums, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = golden("cohorts")
+    N = g["c1_log_theta"].shape[0]
+    assert int(res[4]) == 1 + N * N + 2 * N
+    np.testing.assert_allclose(res[0], g["c1_score"], rtol=1e-12)
+    np.testing.assert_allclose(res[1], g["c1_d_th"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(res[2], g["c1_d_dp"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(res[3], g["c1_d_dm"], rtol=1e-10, atol=1e-13)
+
+
+def test_cohort_cache_guard_notices_in_place_edits():
+    from metmhn_amd import regularized_optimization as ro, synthetic
+    dat = synthetic.mixed_cohort(5, 300, seed=3)
+    c0 = ro._sample_crc(dat)
+    dat2 = dat.copy()
+    dat2[:, -2] = 0                                        # relabel every row in place
+    assert ro._sample_crc(dat2) != c0 and ro._sample_crc(dat.copy()) == c0
+
+
 def _cv_stub_learn(th0, dp0, dm0, train, m_p_corr, penal, w, opt_v=False):
     return th0 + w, dp0, dm0                    # stands in for the optimizer (GPU-only); depends on lambda
 

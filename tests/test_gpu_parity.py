@@ -345,7 +345,8 @@ def test_fp32_engine_close_to_fp64():
 
 def test_fp32_engine_tracks_fp64_engine_on_large_spaces():
     """No CPU oracle finishes k = 18 in seconds: compare the fp32 engine (e_0 pre-scaled by 2^60) with the
-    fp64 engine on the same paired patients; log-probs to 1e-4, gradients to 1e-2 of their norm."""
+    fp64 engine on the same paired patients; log-probs to 1e-4, every gradient component within 2e-3 relative +
+    2e-5 absolute."""
     from metmhn_amd import Engine, synthetic
     n = 18
     lt, dp, dm = synthetic.random_params(n)
@@ -359,8 +360,9 @@ def test_fp32_engine_tracks_fp64_engine_on_large_spaces():
     (lp64, g64, a64, b64), (lp32, g32, a32, b32) = res
     assert np.all(np.isfinite(lp32)) and np.all(np.isfinite(g32))
     np.testing.assert_allclose(lp32, lp64, rtol=1e-4)
-    for x32, x64 in ((g32, g64), (a32, a64), (b32, b64)):
-        assert np.linalg.norm(x32 - x64) <= 1e-2 * np.linalg.norm(x64)
+    for nm, x32, x64 in (("d_theta", g32, g64), ("d_dp", a32, a64), ("d_dm", b32, b64)):
+        err = np.abs(x32 - x64)
+        assert (err <= 2e-3 * np.abs(x64) + 2e-5).all(), f"{nm}: max abs err {err.max():.3e}"
 
 
 def test_cross_val_workflow():
@@ -550,8 +552,9 @@ def test_config1_n12_1000_patients_both_schedules(monkeypatch):
 
 def test_config4_n25_fp32_against_fp64_cpu():
     """BASELINE configs[4] dtype and size: n = k = 25 (2^25-state vectors, 128 MiB fp32 each), engine dtype f32, against
-    oracle/metmhn_fast.c in fp64.  fp32 bar (necessarily looser than 1e-6): log-prob 1e-4 relative, gradients
-    within 1e-2 of their norm.  Also one k = 22 patient: fp32 engine against the fp64 engine."""
+    oracle/metmhn_fast.c in fp64.  fp32 bar (necessarily looser than 1e-6): log-prob 1e-4 relative, EVERY
+    gradient component within 2e-3 relative + 2e-5 absolute (the worst component is printed).  Also one k = 22 patient:
+    fp32 engine against the fp64 engine at the same bar."""
     from oracle import cref
     from metmhn_amd import Engine, synthetic
     n = 25
@@ -565,8 +568,8 @@ def test_config4_n25_fp32_against_fp64_cpu():
     assert np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1]))
     np.testing.assert_allclose(r[0], lp, rtol=1e-4)
     for x32, x64, nm in ((r[1], g, "d_theta"), (r[2], a, "d_dp"), (r[3], b, "d_dm")):
-        for i in range(dat.shape[0]):
-            assert np.linalg.norm(x32[i] - x64[i]) <= 1e-2 * np.linalg.norm(x64[i]), f"{nm} patient {i}"
+        err, tol = _fp32_report(f"n=25 {nm}", x32, x64)
+        assert (err <= tol).all(), nm
     n = 22
     lt, dp, dm = synthetic.random_params(n)
     dat = synthetic.full_k_cohort(n, 1, seed=2022)
@@ -577,8 +580,9 @@ def test_config4_n25_fp32_against_fp64_cpu():
         res.append(e.patient_grads(lt, dp, dm))
         e.close()
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4)
-    for x32, x64 in zip(res[1][1:], res[0][1:]):
-        assert np.linalg.norm(x32 - x64) <= 1e-2 * np.linalg.norm(x64)
+    for nm, x32, x64 in zip(("d_theta", "d_dp", "d_dm"), res[1][1:], res[0][1:]):
+        err, tol = _fp32_report(f"k=22 {nm}", x32, x64)
+        assert (err <= tol).all(), nm
 
 
 def test_partial_diag_scal_golden(golden):
@@ -915,3 +919,122 @@ def test_fused_jacobi_step_at_benchmarked_shape():
                 for b in range(B):
                     ref = lidg * (cref.kronvec(lt, p[b], st, diag=False, transpose=tr) + rhs[b])
                     np.testing.assert_allclose(y[b], ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max(), err_msg=f"k={kk} tr={tr}")
+
+
+def _one_rank_comm(e):
+    """In-library RCCL all-reduce with a one-rank communicator (what MMHN_FORCE_ALLREDUCE=1 attaches): the collective
+    code path of the sharded engine on a single GPU."""
+    from metmhn_amd.engine import unique_id
+    e.comm_init(unique_id(), 0, 1)
+
+
+@pytest.mark.gpu
+def test_config3_rank_shard_n20_50000_patients():
+    """BASELINE configs[3] (n = 20, 50 000 patients over 8 GPUs) as ONE rank sees it: the LPT shard 0 of the 50 000-row
+    cohort (6 250 rows, regularized_optimization.py:256-266 is what shards), evaluated through the pre-combined
+    all-reduce payload with the in-library RCCL all-reduce attached; 8 random rows of the shard against
+    oracle/metmhn_fast.c, and the shard's weighted sums against the sum of its per-patient rows."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic, distributed as D
+    n, P, W = 20, 50000, 8
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
+    parts = D.shard_rows(dat, W)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(P)) and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    rows = dat[parts[0]]
+    assert rows.shape[0] == P // W
+    w, n_full = D.em_weight(float(dat[:, -3].sum()), float(P), 0.5)
+    with Engine(n) as e:
+        e.set_cohort(rows)
+        _one_rank_comm(e)
+        e.cohort_wsums_begin(lt, dp, dm, w)
+        ws = e.cohort_wsums_end()
+        lp, g, gp, gm = e.patient_grads(lt, dp, dm)
+    N = n + 1
+    assert ws.shape == (1 + N * N + 2 * N,) and np.isfinite(ws).all()
+    # every row is a paired (EM) patient: the payload is w times the plain sums of the shard's rows
+    np.testing.assert_allclose(ws[0], w * lp.sum(), rtol=1e-11)
+    np.testing.assert_allclose(ws[1:1 + N * N].reshape(N, N), w * g.sum(axis=0), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ws[1 + N * N:1 + N * N + N], w * gp.sum(axis=0), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ws[1 + N * N + N:], w * gm.sum(axis=0), rtol=1e-9, atol=1e-9)
+    pick = np.random.default_rng(5).choice(rows.shape[0], size=8, replace=False)
+    rlp, rg, ra, rb = cref.fast_patients(lt, dp, dm, rows[pick])
+    np.testing.assert_allclose(lp[pick], rlp, rtol=1e-10)
+    np.testing.assert_allclose(g[pick], rg, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gp[pick], ra, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(gm[pick], rb, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_shard_partial_sums_add_up():
+    """8 LPT shards of a 64-row mixed cohort (all dat types), each evaluated by an engine of its own with the
+    collective attached: the 8 partial buffers add up to the unsharded buffer to 1e-12 - both layouts (raw sums and
+    the pre-combined payload)."""
+    from metmhn_amd import Engine, synthetic, distributed as D
+    n = 7
+    lt, dp, dm = synthetic.random_params(n, seed=21)
+    dat = np.vstack((synthetic.mixed_cohort(n, 48, seed=4, p_event=0.45), synthetic.full_k_cohort(n, 16, seed=9)))
+    w, n_full = D.em_weight(float(dat[:, -3].sum()), float(dat.shape[0]), 0.3)
+    with Engine(n) as e:
+        e.set_cohort(dat)
+        full = e.cohort_sums(lt, dp, dm)
+        e.cohort_wsums_begin(lt, dp, dm, w)
+        wfull = e.cohort_wsums_end()
+    acc, wacc = np.zeros_like(full), np.zeros_like(wfull)
+    for part in D.shard_rows(dat, 8):
+        with Engine(n) as e:
+            e.set_cohort(dat[part])
+            _one_rank_comm(e)
+            acc += e.cohort_sums(lt, dp, dm)
+            e.cohort_wsums_begin(lt, dp, dm, w)
+            wacc += e.cohort_wsums_end()
+    np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(wacc, wfull, rtol=1e-12, atol=1e-12)
+    ref = D.combine_sums(full, n + 1, 0.3)
+    got = D.split_wsums(wacc, n + 1, n_full)
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+
+
+def _fp32_report(tag, x32, x64):
+    """max per-component error of an fp32 gradient against fp64: absolute, and relative to 2e-3 |x| + 2e-5"""
+    err = np.abs(x32 - x64)
+    tol = 2e-3 * np.abs(x64) + 2e-5
+    worst = np.unravel_index(np.argmax(err / tol), err.shape)
+    print(f"[fp32] {tag}: max abs err {err.max():.3e}, worst component {worst}: {x32[worst]:.6e} vs {x64[worst]:.6e} "
+          f"({(err / tol).max():.3f} of the bar)")
+    return err, tol
+
+
+@pytest.mark.gpu
+def test_config4_rank_shard_n25_fp32_multi_batch():
+    """BASELINE configs[4] (n = 25, 10 000 patients, fp32, 8 GPUs) as ONE rank sees it: the 1 250-row LPT shard 0 -
+    2 x 1 250 x 128 MiB of solution vectors do not fit the workspace, so the engine runs it in several batches - with
+    the collective attached; 8 random rows against oracle/metmhn_fast.c (fp64) at the fp32 bar: log-prob 1e-4,
+    every gradient component within 2e-3 relative + 2e-5 absolute; the payload equals the sum of the per-patient rows."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic, distributed as D
+    n, P, W = 25, 10000, 8
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
+    part = D.shard_rows(dat, W)[0]
+    rows = dat[part]
+    assert rows.shape[0] == P // W
+    w, n_full = D.em_weight(float(dat[:, -3].sum()), float(P), 0.5)
+    with Engine(n, dtype="f32") as e:
+        e.set_cohort(rows)
+        _one_rank_comm(e)
+        e.cohort_wsums_begin(lt, dp, dm, w)
+        ws = e.cohort_wsums_end()
+        lp, g, gp, gm = e.patient_grads(lt, dp, dm)
+    N = n + 1
+    assert np.isfinite(ws).all() and np.isfinite(lp).all()
+    np.testing.assert_allclose(ws[0], w * lp.sum(), rtol=1e-9)
+    # (two fp32 evaluations, 1 250 terms per sum: agreement to fp32 rounding of the partial sums)
+    np.testing.assert_allclose(ws[1:1 + N * N].reshape(N, N), w * g.sum(axis=0), rtol=2e-5, atol=2e-5)
+    pick = np.random.default_rng(6).choice(rows.shape[0], size=8, replace=False)
+    rlp, rg, ra, rb = cref.fast_patients(lt, dp, dm, rows[pick])
+    np.testing.assert_allclose(lp[pick], rlp, rtol=1e-4)
+    for tag, x32, x64 in (("d_theta", g[pick], rg), ("d_dp", gp[pick], ra), ("d_dm", gm[pick], rb)):
+        err, tol = _fp32_report(tag, x32, x64)
+        assert (err <= tol).all(), tag
