@@ -1404,8 +1404,9 @@ struct Engine : EngineBase {
     HIPCHECK(hipMemsetAsync(a.p, 0, n16 * 16, stream));
     HIPCHECK(hipMemsetAsync(b.p, 0, n16 * 16, stream));
     if (kind == 1) HIPCHECK(hipMemsetAsync(c.p, 0, n16 * 16, stream));
+    static const int sblocks = std::getenv("MMHN_STREAM_BLOCKS") ? std::atoi(std::getenv("MMHN_STREAM_BLOCKS")) : 256 * 8;
     auto run = [&]() {
-      hipLaunchKernelGGL(k_stream, dim3(256 * 8), dim3(256), 0, stream, a.p, b.p, c.p, n16, kind);
+      hipLaunchKernelGGL(k_stream, dim3(sblocks), dim3(256), 0, stream, a.p, b.p, c.p, n16, kind);
     };
     run();
     hipEvent_t e0, e1;

@@ -8,7 +8,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "_build", "libmetmhn_ref.so")
+# MMHN_ORACLE_DIR: load another build of the two libraries (oracle/Makefile `asan`: the sanitizer build)
+_DIR = os.path.abspath(os.environ["MMHN_ORACLE_DIR"]) if os.environ.get("MMHN_ORACLE_DIR") else os.path.join(_HERE, "_build")
+LIB = os.path.join(_DIR, "libmetmhn_ref.so")
 _f = C.POINTER(C.c_double)
 _i8 = C.POINTER(C.c_int8)
 _lib = None
@@ -17,7 +19,7 @@ _lib = None
 def load(build: bool = True):
     global _lib
     if _lib is None:
-        if build and (not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "metmhn_ref.c"))):
+        if build and not os.environ.get("MMHN_ORACLE_DIR") and (not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "metmhn_ref.c"))):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
         _lib = C.CDLL(LIB)
         _lib.ref_patients.argtypes = [C.c_int, _f, _f, _f, _i8, C.c_int64, C.c_int, C.c_int, C.c_int, _f, _f, _f, _f]
@@ -64,7 +66,7 @@ def kronvec(log_theta, p, state, diag=True, transpose=False):
     return y
 
 
-FAST = os.path.join(_HERE, "_build", "libmetmhn_fast.so")
+FAST = os.path.join(_DIR, "libmetmhn_fast.so")
 _fast = None
 
 
@@ -72,7 +74,7 @@ def load_fast(build: bool = True):
     """oracle/_build/libmetmhn_fast.so: optimised CPU variant (paired rows only; baseline / checker only)."""
     global _fast
     if _fast is None:
-        if build and (not os.path.exists(FAST) or os.path.getmtime(FAST) < os.path.getmtime(os.path.join(_HERE, "metmhn_fast.c"))):
+        if build and not os.environ.get("MMHN_ORACLE_DIR") and (not os.path.exists(FAST) or os.path.getmtime(FAST) < os.path.getmtime(os.path.join(_HERE, "metmhn_fast.c"))):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
         _fast = C.CDLL(FAST)
         _fast.fast_patients.argtypes = [C.c_int, _f, _f, _f, _i8, C.c_int64, C.c_int, _f, _f, _f, _f]
