@@ -1284,7 +1284,7 @@ struct Engine : EngineBase {
     DevArr<Desc> dd;
     DevArr<int2> map, live;                       // every tile; the tiles with entries (what the plain product launches)
     DevArr<int> zmap;                             // per live tile: the structurally zero tile its workgroup clears, -1: none
-    DevArr<T> tab, hxt, hxl;                      // hxt: tile-bit factors for `map`, hxl: for `live`
+    DevArr<T> tab, hxl;                           // hxl: tile-bit factors of the live tiles
   };
   void kv_setup(KvBatch& kb, const Desc& d0, long long batch) {
     REQUIRE(batch >= 1, "batch must be positive");
@@ -1324,19 +1324,16 @@ struct Engine : EngineBase {
     prep(kb.dd.p, 1, kb.tab.p);                    // one table: every vector lives in the same space
     kb.use_kv = d0.k > TB && kv_version == 2;
     if (kb.use_kv) {
-      kb.hxt.alloc(mp.size() * (size_t)d0.k);
       kb.hxl.alloc(lv.size() * (size_t)d0.k);
-      hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.ntiles), dim3(64), 0, stream, kb.dd.p, kb.map.p, kb.tab.p, kb.hxt.p, d0.k);
       hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.nlive), dim3(64), 0, stream, kb.dd.p, kb.live.p, kb.tab.p, kb.hxl.p, d0.k);
       HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipStreamSynchronize(stream));
   }
-  // plain product: the live tiles, each seeded one clearing its structurally zero counterpart - all of y is written;
-  // fused Jacobi step (lidg, rhs given): every tile
+  // the live tiles, each seeded one also filling its counterpart without entries of Q_off (zeros; lidg * rhs in the
+  // fused Jacobi step): all of y is written by one launch
   void kv_launch(const KvBatch& kb, bool tr, const T* p, T* y, const T* lidg = nullptr, const T* rhs = nullptr) {
-    if (kb.use_kv && lidg) launch_kv(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, kb.tab.p, kb.hxt.p, nullptr, lidg, rhs);
-    else if (kb.use_kv) launch_kv(tr, kb.dd.p, kb.live.p, kb.nlive, kb.d.k, p, y, kb.tab.p, kb.hxl.p, kb.zmap.p);
+    if (kb.use_kv) launch_kv(tr, kb.dd.p, kb.live.p, kb.nlive, kb.d.k, p, y, kb.tab.p, kb.hxl.p, kb.zmap.p, lidg, rhs);
     else launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, kb.d.k, p, y, lidg, rhs, 0, nullptr, 0, kb.tab.p);
   }
   void api_kronvec_batched(const Desc& d, long long batch, const double* p, double* y, bool diag, bool tr) {

@@ -488,8 +488,8 @@ __global__ __launch_bounds__(64) void k_hx(const Desc* __restrict__ descs, const
 // zmap (optional): zmap[i] = a tile of the same vector in which Q_off has no entries (a seed = 0 tile without PT == MT
 //   states, -1: none) that the workgroup of list entry i clears on its way - the product then fills ALL of y with a
 //   launch over the live tiles only (no memset, no workgroups that do nothing but store zeros).
-// JAC: fused Jacobi step y = lidg * (Q_off p + rhs)  (likelihood.py:253-255); every tile is launched (a tile without
-//   entries still gets lidg * rhs).
+// JAC: fused Jacobi step y = lidg * (Q_off p + rhs)  (likelihood.py:253-255); a tile without entries gets lidg * rhs
+//   (from its live counterpart's workgroup when zmap is given, else from its own).
 template <typename T, bool TR, int TPW, bool JAC>
 __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict__ descs, const int2* __restrict__ map, int ntiles,
                                                          const T* __restrict__ p, T* __restrict__ y,
@@ -556,13 +556,18 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
 #pragma unroll
       for (int j = 0; j < NJ; ++j) vnext[j] = (p + basen + (Hn << t))[(((uint32_t)(wave * NJ + j) << 6) | (uint32_t)lane)];
     }
-    if (!JAC && zmap) {                                        // the structurally zero tile this workgroup clears
+    if (zmap) {                                                // the tile without entries of Q_off this workgroup fills
       const int zt = sgpr(zmap[blk]);
       if (zt >= 0) {
         for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += KSB * PER) {
-          T* dst = y + base + ((uint32_t)zt << t) + e;
-          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(zero4) : "memory");
+          const long long xi = base + ((uint32_t)zt << t) + e;
+          if (JAC) {                                           // lidg * rhs: the row of Q_off is empty there
+#pragma unroll
+            for (int u = 0; u < PER; ++u) y[xi + u] = lidg[xi + u] * rhs[xi + u];
+          } else {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(y + xi), "v"(zero4) : "memory");
+          }
         }
       }
     }

@@ -16,8 +16,36 @@ _i8 = C.POINTER(C.c_int8)
 _lib = None
 
 
+def _cpu_share() -> int:
+    """Cores this process may really use: affinity, capped by the cgroup quota and by 16.  The GPU boxes show every core
+    of the host while the container owns a fraction: an OpenMP team of the visible count spins against itself (a 1 s
+    ref_kronvec then takes minutes)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(cores, 16))
+
+
+def _limit_threads():
+    if os.environ.get("OMP_NUM_THREADS"):
+        return
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(_cpu_share())
+    except Exception:
+        pass
+
+
 def load(build: bool = True):
     global _lib
+    _limit_threads()
     if _lib is None:
         if build and not os.environ.get("MMHN_ORACLE_DIR") and (not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "metmhn_ref.c"))):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
@@ -73,6 +101,7 @@ _fast = None
 def load_fast(build: bool = True):
     """oracle/_build/libmetmhn_fast.so: optimised CPU variant (paired rows only; baseline / checker only)."""
     global _fast
+    _limit_threads()
     if _fast is None:
         if build and not os.environ.get("MMHN_ORACLE_DIR") and (not os.path.exists(FAST) or os.path.getmtime(FAST) < os.path.getmtime(os.path.join(_HERE, "metmhn_fast.c"))):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
