@@ -440,6 +440,7 @@ struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- parameters
   void build_params(const double* lt, const double* ldp, const double* ldm) {
+    REQUIRE(!sums_pending, "an evaluation begun with mmhn_cohort_sums_begin has not been collected (its parameter upload may still be in flight)");
     // exp(theta_ij - d_j) = exp(theta_ij) * exp(-d_j): N^2 + 2N exponentials per evaluation instead of 3 N^2 (this runs
     // on the host before the first launch of every evaluation - 26 us of a 400 us LUAD evaluation as three full passes)
     std::vector<double> eth((size_t)N * N), enp(N, 1.0), enm(N, 1.0);

@@ -57,7 +57,7 @@ __host__ __device__ inline int spatient_rows(int maxk) { return maxk > 6 ? 1 << 
 template <typename T>
 __host__ __device__ inline size_t spatient_lds(int N, int maxk) {
   return ((size_t)N * (spatient_lstride(maxk) + spatient_rows(maxk) + 16 + 1) + 4 * 64 + 2 * 16 + ((size_t)3 << maxk) + 64) * sizeof(T) +
-         (64 + TB + 2) * sizeof(int) + DESC_PAD + (sizeof(uint16_t) << maxk);
+         (64 + TB + 2) * sizeof(int) + 8 + DESC_PAD + (sizeof(uint16_t) << maxk);
 }
 
 // SPB threads work on one patient; PPB patients share a workgroup (PPB > 1 only with SPB = 64: a wave per patient, no
@@ -97,7 +97,9 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
   T* dml = dpl + 16;
   int* lev = reinterpret_cast<int*>(dml + 16);            // event of local bit l
   int* loff = lev + 64;                                    // offsets of the popcount levels in pml
-  Desc& dsh = *reinterpret_cast<Desc*>(loff + TB + 2);     // the problem's descriptor (global reads off the critical loops)
+  // the problem's descriptor (global reads off the critical loops); 8-byte aligned whatever the element counts before it
+  // (its offsets are 64-bit: for T = float an odd number of elements would put it on a 4-byte boundary)
+  Desc& dsh = *reinterpret_cast<Desc*>((reinterpret_cast<uintptr_t>(loff + TB + 2) + 7u) & ~(uintptr_t)7u);
   uint16_t* pml = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(&dsh) + DESC_PAD);   // states by popcount
   const int pidx = block * PPB + pslot;
   if (pidx >= npl) return;

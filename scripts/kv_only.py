@@ -20,5 +20,8 @@ st = synthetic.full_k_cohort(n, 1, k=k, seed=2000 + n)[0, :2 * n + 1]
 e = Engine(n)
 V = 2 ** int(st.sum()) * 8
 for name, tr, jac, mult in (("kronvec", 0, 0, 2), ("kronvec_T", 1, 0, 2), ("jacobi_step", 0, 1, 4)):
-    ms = min(e.bench_kronvec(lt, st, batch, iters, transpose=tr, jacobi=jac) for _ in range(3))
-    print(f"{name:12s} {ms:8.4f} ms/launch  {mult * V * batch / ms / 1e9:7.3f} TB/s alg  frac of 8 TB/s {mult * V * batch / ms / 1e9 / 8:.3f}")
+    ms, live, tot = min(e.bench_kronvec(lt, st, batch, iters, transpose=tr, jacobi=jac, tiles=True) for _ in range(3))
+    tile_b = V * batch / tot
+    live_b = (live + tot) * tile_b if not jac else (live + 3 * tot) * tile_b      # bytes the launch has to move
+    print(f"{name:12s} {ms:8.4f} ms/launch  {mult * V * batch / ms / 1e9:7.3f} TB/s on SURVEY 8(d) bytes ({mult * V * batch / ms / 1e9 / 8:.3f} of 8 TB/s)"
+          f"  {live_b / ms / 1e9:7.3f} TB/s on the bytes it must move ({live_b / ms / 1e9 / 8:.3f});  {live} of {tot} tiles carry values")

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/r2_pmc/*_counter_collection.csv -> profiles/r2_traffic.json (read by bench.py, marked "recorded offline").
+"""profiles/<tag>_pmc/*_counter_collection.csv -> profiles/<tag>_traffic.json (read by bench.py, marked "recorded offline").
+
+    python scripts/make_traffic_json.py [tag=r3]
+
 
 The PMC passes are separate runs (scripts/profile_round.sh): FETCH_SIZE and WRITE_SIZE over scripts/eval_only.py 5000
 (two evaluations of the bench cohort) and over scripts/kv_only.py (batched kronvec, 64 vectors of 2^20 states).
@@ -12,8 +15,13 @@ import glob
 import json
 import os
 
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PMC = os.path.join(ROOT, "profiles", "r2_pmc")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
+PMC = os.path.join(ROOT, "profiles", f"{TAG}_pmc")
+sys.path.insert(0, ROOT)
 
 
 def per_launch(tag, counter):
@@ -28,7 +36,14 @@ def per_launch(tag, counter):
 
 def main():
     P = 5000
-    out = {"_comment": __doc__.strip().split("\n\n")[1].replace("\n", " ")}
+    from bench import csrc_sha16
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = "?"
+    out = {"_comment": __doc__.strip().split("\n\n")[2].replace("\n", " "),
+           # the tree the PMC passes were taken on: bench.py quotes these figures only while csrc/ is unchanged
+           "source": {"git_head": head, "csrc_sha16": csrc_sha16()}}
     ef, ew = per_launch("eval_f", "FETCH_SIZE"), per_launch("eval_w", "WRITE_SIZE")
     ek = {}
     for name, prefix in (("psolve_fwd", "k_psolve2<double, false"), ("psolve_adj", "k_psolve2<double, true"), ("pclass", "k_pclass<double>")):
@@ -42,14 +57,15 @@ def main():
     kf, kw = per_launch("kv_f", "FETCH_SIZE"), per_launch("kv_w", "WRITE_SIZE")
     alg = {"kronvec": 2, "kronvec_T": 2, "jacobi_step": 4}
     kv = {}
-    for name, kern in (("kronvec", "k_kv<double, false, 1>"), ("kronvec_T", "k_kv<double, true, 1>"), ("jacobi_step", "k_sweep<double, false>")):
+    for name, kern in (("kronvec", "k_kv<double, false, 1, false>"), ("kronvec_T", "k_kv<double, true, 1, false>"),
+                       ("jacobi_step", "k_kv<double, false, 1, true>")):
         if kern not in kf:
             continue
         kv[name] = {"kernel": kern, "fetch_kb_reported": kf[kern], "write_kb": kw[kern], "bytes_per_launch": (2 * kf[kern] + kw[kern]) * 1024,
                     "alg_bytes_per_launch": alg[name] * 64 * (2 ** 20) * 8}
         kv[name]["moved_over_alg"] = kv[name]["bytes_per_launch"] / kv[name]["alg_bytes_per_launch"]
     out["kronvec"] = kv
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r2_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_traffic.json"), "w"), indent=1)
     print(json.dumps({k: round(v["bytes_per_patient"] / 1e6, 2) for k, v in ek.items()}))
     print(json.dumps({k: round(v["moved_over_alg"], 3) for k, v in kv.items()}))
 

@@ -24,4 +24,12 @@ for pass in "eval_f FETCH_SIZE eval_only.py 5000" "eval_w WRITE_SIZE eval_only.p
   timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$name -- python3 $R/scripts/"$@" > /dev/null 2>&1
   cp /tmp/pmc_$name/*/*counter_collection.csv $R/gpurun_out/${tag}_pmc/${name}_counter_collection.csv
 done
+# instruction mix of the two joint-solve implementations: default tile kernels, then MMHN_MSOLVE=1
+for v in 0 1; do
+  export MMHN_MSOLVE=$v
+  bash $R/scripts/pmc_eval.sh ${tag}_solve${v}_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" 5000 > $R/gpurun_out/${tag}_solve${v}_a.txt 2>&1
+  bash $R/scripts/pmc_eval.sh ${tag}_solve${v}_b "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_BUSY_CYCLES" 5000 > $R/gpurun_out/${tag}_solve${v}_b.txt 2>&1
+done
+unset MMHN_MSOLVE
+cat $R/gpurun_out/${tag}_solve0_a.txt $R/gpurun_out/${tag}_solve0_b.txt $R/gpurun_out/${tag}_solve1_a.txt $R/gpurun_out/${tag}_solve1_b.txt | grep "k_psolve2\|k_msolve" > $R/gpurun_out/${tag}_msolve_counters.txt
 ls -la $R/gpurun_out/${tag}_pmc
