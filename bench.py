@@ -336,7 +336,7 @@ def main():
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "dtype": a.dtype, "data": "synthetic" if a.workload == "full-k" else "LUAD-reduced genotypes (derived fixture), indep() parameters",
             "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
-                       "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {4 + 2 * N * N + 3 * N} f64 per eval "
+                       "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
                        "solver": os.environ.get("MMHN_SOLVER", "substitution (k_psolve per patient, k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
