@@ -1038,3 +1038,30 @@ def test_config4_rank_shard_n25_fp32_multi_batch():
     for tag, x32, x64 in (("d_theta", g[pick], rg), ("d_dp", gp[pick], ra), ("d_dm", gm[pick], rb)):
         err, tol = _fp32_report(tag, x32, x64)
         assert (err <= tol).all(), tag
+
+
+@pytest.mark.gpu
+def test_batched_kronvec_and_jacobi_step_fp32():
+    """The fp32 instantiations of the batched product and of the fused Jacobi step (BASELINE configs[4] runs the engine in
+    fp32) against the fp64 CPU port at k = 16: 2e-5 of the vector's largest entry."""
+    from oracle import cref, metmhn_oracle as O
+    from metmhn_amd import Engine, synthetic
+    cref.load()
+    n = kk = 16
+    lt, dp, dm = synthetic.random_params(n, seed=41)
+    st = synthetic.full_k_cohort(n, 1, k=kk, seed=541)[0, :2 * n + 1]
+    rng = np.random.default_rng(79)
+    p = rng.random((3, 2 ** kk)) + 0.01
+    rhs = rng.random((3, 2 ** kk))
+    ones = np.ones(2 ** kk)
+    lidg = 1.0 / (O.diag_scal_p(dp, st, ones) + O.diag_scal_m(dm, st, ones) - O.kron_diag(lt, st, kk))
+    with Engine(n, dtype="f32") as e:
+        for tr in (False, True):
+            y = e.kronvec_batched(lt, p, st, diag=False, transpose=tr)
+            z = e.jacobi_step_batched(lt, dp, dm, p, rhs, st, transpose=tr)
+            assert np.isfinite(y).all() and np.isfinite(z).all()
+            for b in range(3):
+                ref = cref.kronvec(lt, p[b], st, diag=False, transpose=tr)
+                np.testing.assert_allclose(y[b], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+                refz = lidg * (ref + rhs[b])
+                np.testing.assert_allclose(z[b], refz, rtol=0, atol=2e-5 * np.abs(refz).max())
