@@ -304,8 +304,7 @@ def test_bench_line_contract():
     import glob
     import json
     ast.parse(open(os.path.join(ROOT, "bench.py")).read())
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r1_v*_bench_line.json")),
-                   key=lambda p: int(os.path.basename(p).split("_")[1][1:]))
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]_bench_line.json")))      # the latest round's line
     d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -321,3 +320,12 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and abs(d["value"] - d["n_gpus"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    # round 3: metric 2 with its three byte counts, the Jacobi pricing of SURVEY 8(d), per-rank times, the PMC source stamp
+    for name in ("kronvec", "kronvec_T", "jacobi_step"):
+        kv = d["kronvec"][name]
+        for k in ("ms_per_launch", "frac_of_peak", "frac_of_peak_live", "tiles_per_launch", "tiles_with_entries"):
+            assert k in kv, (name, k)
+        assert 0 < kv["frac_of_peak_live"] <= kv["frac_of_peak"] < 1 and kv["tiles_with_entries"] <= kv["tiles_per_launch"]
+    assert d["eval_floor"]["B_pat_equivalent"]["bytes_per_patient"] == 151 * 2 ** 20 * 8
+    assert d["rank_ms_per_step"]["max"] >= d["rank_ms_per_step"]["min"] > 0
+    assert "csrc" in r.get("traffic_source", "") and r["traffic"] > r["alg_bytes_per_launch"]
