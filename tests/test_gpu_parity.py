@@ -281,6 +281,22 @@ def test_empty_and_error_paths(engines):
         e.set_cohort(np.array([[1, 1, 0, 0, 0, 0, 0, 1, 3]], dtype=np.int8))       # paired row without seeding
     with pytest.raises(RuntimeError):
         Engine(3, device=99)
+    # round 3 entry points: shapes are checked before anything reaches the device; an evaluation begun in two halves must be
+    # collected with the matching _end, and nothing else may start in between
+    st = np.array([1, 1, 0, 1, 1, 0, 1], dtype=np.int8)                            # k = 5
+    lt = np.zeros((4, 4))
+    with pytest.raises(ValueError):
+        e.kronvec_batched(lt, np.ones((2, 16)), st)
+    with pytest.raises(ValueError):
+        e.jacobi_step_batched(lt, np.zeros(4), np.zeros(4), np.ones((2, 32)), np.ones((3, 32)), st)
+    y = e.kronvec_batched(lt, np.ones((2, 32)), st, diag=False)
+    np.testing.assert_allclose(y[0], e.kronvec(lt, np.ones(32), st, diag=False), rtol=1e-13)
+    e.set_cohort(np.array([[1, 1, 0, 1, 1, 0, 1, 1, 3]], dtype=np.int8))
+    e.cohort_wsums_begin(lt, np.zeros(4), np.zeros(4), 1.0)
+    with pytest.raises(RuntimeError):
+        e.cohort_sums_end()                                                        # begun as wsums
+    ws = e.cohort_wsums_end()
+    assert ws.shape == (1 + 16 + 8,) and np.isfinite(ws).all()
 
 
 def test_substitution_solver_matches_jacobi_iteration(monkeypatch):
