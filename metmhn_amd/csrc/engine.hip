@@ -102,9 +102,12 @@ struct Batch {
   // small-space path (small.h): patients by size class of their largest single-tumour space; sp_ok: every one fits a tile
   // [0]: patients that are their own single-tumour problem (dat types 0-2: nothing of the joint path feeds them),
   // [1]: paired patients (their single-tumour problems are marginals of the joint forward solution)
-  std::vector<int> sp_list[2][SP_NCLASS];
-  DevArr<int> d_sp_list[2][SP_NCLASS];
+  // [0]: patients that are their own problem, [1]: paired rows, [2]: the paired rows with both marginal problems whose
+  // class has a side-by-side kernel (small.h PAIR) - taken out of [1]
+  std::vector<int> sp_list[3][SP_NCLASS];
+  DevArr<int> d_sp_list[3][SP_NCLASS];
   bool sp_ok = false;
+  int mk1p = 9;                  // bits the 256-thread class of the paired rows is sized for (spatient_class_maxk(1) or up to 10)
   std::vector<int> paired;       // patients with a joint problem (k_gather_marg runs over these only)
   DevArr<int> d_paired;
   // matrix path (msolve.h): every joint problem of the batch qualifies -> the solves run in the class-sorted layout
@@ -282,6 +285,51 @@ __global__ void k_pack_wsums(const double* __restrict__ sums, int N, double w, d
     o[e] = e < 1 + NN + N ? w * em[e] + nm[e] : w * em[e];          // (d_d_m has no NM part, :266)
 }
 
+// host <-> device traffic of an evaluation without the copy engine: the parameters are read from, and the result is
+// written to, pinned host memory by kernels of the evaluation's own queue.  (A hipMemcpyAsync in front of the first
+// launch costs the hand-over between the copy engine and the compute queue - on a 0.4 ms evaluation of a small cohort
+// ~60 us passed between the 27 KB upload and the first kernel - and the download the same at the other end.)
+__global__ void k_copy_words(const uint4* __restrict__ src, uint4* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+// ... and the head of an evaluation in ONE launch: the parameter upload, the cleared cohort sums and the cleared gradient
+// work arrays of the first batch (three launches otherwise, each a few us of queue latency on a short evaluation)
+__global__ void k_begin_eval(const uint4* __restrict__ src, uint4* __restrict__ dst, int n, double* __restrict__ sums, int nsums,
+                             uint4* __restrict__ z, long long nz) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+  if (i0 < n) dst[i0] = src[i0];
+  if (i0 < nsums) sums[i0] = 0.0;
+  for (long long i = i0; i < nz; i += step) z[i] = uint4{0u, 0u, 0u, 0u};
+}
+
+// k_reduce_parts of the LAST batch and the packing in one launch: thread e adds the chunk sums of both classes in chunk
+// order (as k_reduce_parts does), keeps sums[] current and writes its entries of the packed buffer
+// (mode 1: k_pack_sums layout, a = n_em, b = n_pat; mode 2: k_pack_wsums, a = w)
+__global__ __launch_bounds__(BLOCK) void k_reduce_parts_pack(const double* __restrict__ part, int stride, int nelem, int nchunk,
+                                                             double* sums, int mode, int N, double a, double b,
+                                                             double* __restrict__ o) {
+  const int e = blockIdx.x * BLOCK + threadIdx.x;
+  if (e >= stride) return;
+  double em = sums[e], nm = sums[stride + e];
+  if (e < nelem) {
+    double acc0 = 0, acc1 = 0;
+#pragma unroll 8
+    for (int c = 0; c < nchunk; ++c) {
+      acc0 += part[((long long)c * 2 + 0) * stride + e];
+      acc1 += part[((long long)c * 2 + 1) * stride + e];
+    }
+    em += acc0; nm += acc1;
+    sums[e] = em; sums[stride + e] = nm;
+  }
+  const int NN = N * N;
+  if (mode == 2) { o[e] = e < 1 + NN + N ? a * em + nm : a * em; return; }
+  if (e == 0) { o[0] = em; o[1] = nm; o[2] = a; o[3] = b; }
+  else if (e < 1 + NN) { o[4 + (e - 1)] = em; o[4 + NN + (e - 1)] = nm; }
+  else if (e < 1 + NN + N) { o[4 + 2 * NN + (e - 1 - NN)] = em; o[4 + 2 * NN + N + (e - 1 - NN)] = nm; }
+  else o[4 + 2 * NN + 2 * N + (e - 1 - NN - N)] = em;
+}
+
 template <typename T>
 struct Engine : EngineBase {
   int n = 0, N = 0;
@@ -289,6 +337,9 @@ struct Engine : EngineBase {
   DevArr<Params<T>> d_par;
   Params<T>* h_par = nullptr;         // pinned: the per-evaluation upload is a true async copy
   double* h_abi = nullptr;            // pinned landing buffer of the result download
+  void* h_par_dev = nullptr;          // device views of the two pinned buffers
+  double* h_abi_dev = nullptr;
+  bool zero_copy = true;              // MMHN_ZEROCOPY=0: hipMemcpyAsync up and down instead
   // HIP events around the dominant kernels (mmhn_get_counters): an event record costs ~5 us of host time, which a short
   // evaluation cannot afford (it is bound by the host's issue rate) - only batches of at least 2^24 states are timed
   bool time_kernels = true;
@@ -321,6 +372,8 @@ struct Engine : EngineBase {
   hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
   int kv_version = 2;           // MMHN_KV=1: the round-1 kronvec kernel (k_sweep) also for plain products on multi-tile spaces
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
+  int prep_split_max = 2048;    // MMHN_PREP_SPLIT: problems up to which k_prep / k_pclass run a workgroup per table / class pass
+  bool pair_small = true;       // MMHN_PAIR_SMALL=0: the two marginal problems of a paired row one after the other
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
@@ -343,6 +396,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     d_par.alloc(NPSET);
     HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_par), NPSET * sizeof(Params<T>), hipHostMallocDefault));
+    HIPCHECK(hipHostGetDevicePointer(&h_par_dev, h_par, 0));
+    static_assert(sizeof(Params<T>) % sizeof(uint4) == 0, "parameter block: whole 16-byte words");
     sums.alloc(2 * stride());
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
@@ -369,6 +424,9 @@ struct Engine : EngineBase {
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
+      if (const char* sp = std::getenv("MMHN_PAIR_SMALL")) pair_small = std::atoi(sp) != 0;
+      if (const char* sp = std::getenv("MMHN_ZEROCOPY")) zero_copy = std::atoi(sp) != 0;
+      if (const char* sp = std::getenv("MMHN_PREP_SPLIT")) prep_split_max = std::atoi(sp);
       if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
       if (const char* ms = std::getenv("MMHN_MSOLVE")) msolve_mode = std::atoi(ms);
       std::vector<uint16_t> rt(MROWS), rk(MROWS);
@@ -439,7 +497,7 @@ struct Engine : EngineBase {
   int stride() const { return 1 + N * N + 2 * N; }
 
   // ---------------------------------------------------------------- parameters
-  void build_params(const double* lt, const double* ldp, const double* ldm) {
+  void build_params(const double* lt, const double* ldp, const double* ldm, bool upload = true) {
     REQUIRE(!sums_pending, "an evaluation begun with mmhn_cohort_sums_begin has not been collected (its parameter upload may still be in flight)");
     // exp(theta_ij - d_j) = exp(theta_ij) * exp(-d_j): N^2 + 2N exponentials per evaluation instead of 3 N^2 (this runs
     // on the host before the first launch of every evaluation - 26 us of a 400 us LUAD evaluation as three full passes)
@@ -464,14 +522,24 @@ struct Engine : EngineBase {
         P.dm[i] = (T)(ldm ? std::exp(ldm[i]) : 1.0);
       }
     }
-    HIPCHECK(hipMemcpyAsync(d_par.p, h_par, NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
+    if (!upload) return;                                   // (the caller's first launch carries it: k_begin_eval)
+    if (zero_copy) {
+      const int nw = (int)(NPSET * sizeof(Params<T>) / sizeof(uint4));
+      hipLaunchKernelGGL(k_copy_words, dim3((nw + 255) / 256), dim3(256), 0, stream, static_cast<const uint4*>(h_par_dev),
+                         reinterpret_cast<uint4*>(d_par.p), nw);
+      HIPCHECK(hipGetLastError());
+    } else {
+      HIPCHECK(hipMemcpyAsync(d_par.p, h_par, NPSET * sizeof(Params<T>), hipMemcpyHostToDevice, stream));
+    }
   }
 
   // ---------------------------------------------------------------- launches
   size_t sweep_lds(int maxk) const { return DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)std::max(maxk, 1) * 64) * sizeof(T); }
-  void prep(const Desc* descs, int nprob, T* tab) {
+  // joint: a workgroup per table of a problem (three class tables + the rate tables, k_prep) when the launch is short
+  // enough for its length to be one workgroup's chain; large cohorts keep one workgroup per problem
+  void prep(const Desc* descs, int nprob, T* tab, bool joint = false) {
     if (nprob == 0) return;
-    hipLaunchKernelGGL((k_prep<T>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    hipLaunchKernelGGL((k_prep<T>), dim3(nprob, joint && nprob <= prep_split_max ? 4 : 1), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
   }
 
@@ -895,7 +963,7 @@ struct Engine : EngineBase {
       b.paired.clear();
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) if (b.pats[pi_].j >= 0) b.paired.push_back((int)pi_);
       up(b.d_paired, b.paired);
-      for (int w = 0; w < 2; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
+      for (int w = 0; w < 3; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) {
         const PatRec& pr = b.pats[pi_];
         int ks = -1;
@@ -904,7 +972,22 @@ struct Engine : EngineBase {
         if (ks > TB) { b.sp_ok = false; break; }
         int c = 0;
         while (ks > spatient_class_maxk(c)) ++c;
-        b.sp_list[pr.j >= 0 ? 1 : 0][c].push_back((int)pi_);
+        const bool side_by_side = pair_small && pr.j >= 0 && pr.s[0] >= 0 && pr.s[1] >= 0 && c < 2;
+        b.sp_list[side_by_side ? 2 : pr.j >= 0 ? 1 : 0][c].push_back((int)pi_);
+      }
+      // paired rows of the 1024-thread class: when they are few and of at most 10 bits they ride in the merged 256-thread
+      // launch (its LDS sized for them) - on a small cohort their own launch is a side stream, a fork and a join
+      // (~20 us of queue latency) for a handful of patients
+      b.mk1p = spatient_class_maxk(1);
+      if (pair_small && b.sp_ok && !b.sp_list[1][2].empty() && b.sp_list[1][2].size() <= 16) {
+        int mk = 0;
+        for (int pi_ : b.sp_list[1][2])
+          for (int part = 0; part < 2; ++part) if (b.pats[pi_].s[part] >= 0) mk = std::max(mk, b.dS[b.pats[pi_].s[part]].k);
+        if (mk <= 10) {
+          for (int pi_ : b.sp_list[1][2]) b.sp_list[b.pats[pi_].s[0] >= 0 && b.pats[pi_].s[1] >= 0 ? 2 : 1][1].push_back(pi_);
+          b.sp_list[1][2].clear();
+          b.mk1p = mk;
+        }
       }
       {
         // largest spaces first: the waves of one workgroup (class 0: one patient each) then finish together and the
@@ -915,13 +998,13 @@ struct Engine : EngineBase {
           for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) ks = std::max(ks, 64 * b.dS[pr.s[part]].k + (pr.s[0] >= 0 && pr.s[1] >= 0 ? 32 : 0) + pr.kind);
           return ks;
         };
-        for (int w = 0; w < 2; ++w)
+        for (int w = 0; w < 3; ++w)
           for (int c = 0; c < SP_NCLASS; ++c)
             std::stable_sort(b.sp_list[w][c].begin(), b.sp_list[w][c].end(), [&](int x, int y) { return ksize(x) > ksize(y); });
       }
-      for (int w = 0; w < 2; ++w)
+      for (int w = 0; w < 3; ++w)
         for (int c = 0; c < SP_NCLASS; ++c) {
-          const size_t need_c = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (c == 0 ? SP_PPB0 : 1);
+          const size_t need_c = (spatient_lds<T>(N, c == 1 && w ? b.mk1p : spatient_class_maxk(c)) + 15) / 16 * 16 * (c == 0 ? SP_PPB0 : w == 2 ? 2 : 1) + 64;
           if (!b.sp_list[w][c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
           up(b.d_sp_list[w][c], b.sp_list[w][c]);
         }
@@ -972,26 +1055,39 @@ struct Engine : EngineBase {
   // paired ones (after k_gather_marg).  The size classes are independent of each other.
   // Streams: the own-problem launches go to side[0], next to the joint path on the main stream, and are joined before the
   // assembly; of the paired launches the 1024-thread class goes to side[1], the merged one stays on the main stream.
-  bool small_forked[2] = {false, false};
+  bool small_forked[2] = {false, false}, fork_recorded[2] = {false, false};
+  // the point of the main stream the side launches of `which` wait for (recorded ahead of time when launches of the
+  // critical chain are to be issued first: the host needs ~25 us for a fork, the launches and the join record)
+  void small_fork(int which) {
+    HIPCHECK(hipEventRecord(ev_fork[which], stream));
+    fork_recorded[which] = true;
+  }
   void small_classes(const Batch& b, int which, bool grad) {
     const int n0 = (int)b.sp_list[which][0].size(), n1 = (int)b.sp_list[which][1].size(), n2 = (int)b.sp_list[which][2].size();
-    const int mk0 = spatient_class_maxk(0), mk1 = spatient_class_maxk(1), mk2 = spatient_class_maxk(2);
+    const int np0 = which ? (int)b.sp_list[2][0].size() : 0, np1 = which ? (int)b.sp_list[2][1].size() : 0;
+    const int mk0 = spatient_class_maxk(0), mk1 = which ? b.mk1p : spatient_class_maxk(1), mk2 = spatient_class_maxk(2);
     const bool on_side = which == 0 ? (n0 + n1 + n2 > 0) : n2 > 0;
     hipStream_t sd = side[which];
     if (on_side) {
-      HIPCHECK(hipEventRecord(ev_fork[which], stream));
+      if (!fork_recorded[which]) HIPCHECK(hipEventRecord(ev_fork[which], stream));
       HIPCHECK(hipStreamWaitEvent(sd, ev_fork[which], 0));
     }
+    fork_recorded[which] = false;
 #define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, rhsS.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
-    if (n2) {
+    auto big_class = [&]() {
+      if (!n2) return;
       const size_t lds = (spatient_lds<T>(N, mk2) + 15) / 16 * 16;
       hipLaunchKernelGGL((k_spatient<T, 1024, 1>), dim3(n2), dim3(1024), lds, sd, b.d_sp_list[which][2].p, n2, SP_TAIL, mk2, N, grad ? 1 : 0);
       HIPCHECK(hipGetLastError());
-    }
-    if (n0 + n1) {
-      const size_t lds = std::max((spatient_lds<T>(N, mk0) + 15) / 16 * 16 * SP_PPB0, n1 ? (spatient_lds<T>(N, mk1) + 15) / 16 * 16 : 0);
-      hipLaunchKernelGGL((k_spatient2<T>), dim3((n0 + SP_PPB0 - 1) / SP_PPB0 + n1), dim3(256), lds, which == 0 ? sd : stream,
-                         b.d_sp_list[which][0].p, n0, mk0, b.d_sp_list[which][1].p, n1, mk1, SP_TAIL, N, grad ? 1 : 0);
+    };
+    big_class();
+    if (n0 + n1 + np0 + np1) {
+      const size_t s0 = (spatient_lds<T>(N, mk0) + 15) / 16 * 16, s1 = (spatient_lds<T>(N, mk1) + 15) / 16 * 16;
+      const size_t lds = std::max(s0 * SP_PPB0, n1 + np1 ? s1 * (np1 ? 2 : 1) : 0) + 64;
+      const int nblk = (n0 + SP_PPB0 - 1) / SP_PPB0 + n1 + (np0 + SP_PPB0 / 2 - 1) / (SP_PPB0 / 2) + np1;
+      hipLaunchKernelGGL((k_spatient2<T>), dim3(nblk), dim3(256), lds, which == 0 ? sd : stream,
+                         b.d_sp_list[which][0].p, n0, mk0, b.d_sp_list[which][1].p, n1, mk1,
+                         b.d_sp_list[2][0].p, np0, b.d_sp_list[2][1].p, np1, SP_TAIL, N, grad ? 1 : 0);
       HIPCHECK(hipGetLastError());
     }
 #undef SP_TAIL
@@ -1008,9 +1104,24 @@ struct Engine : EngineBase {
                 double* host_out) {
     REQUIRE(!sums_pending, "an evaluation begun with mmhn_cohort_sums_begin has not been collected");
     auto t0 = std::chrono::steady_clock::now();
-    build_params(lt, ldp, ldm);
     const int st = stride();
-    HIPCHECK(hipMemsetAsync(sums.p, 0, 2 * st * sizeof(double), stream));
+    // the head of the evaluation: parameters up, cohort sums and the first batch's gradient work arrays cleared
+    bool head_done = false;
+    if (zero_copy && !batches.empty()) {
+      build_params(lt, ldp, ldm, false);
+      const Batch& b0 = batches.front();
+      const long long nz = grad && !b0.dJ.empty() ? zarena_elems((long long)b0.dJ.size(), b0.asize, N) * (long long)sizeof(T) / 16 : 0;
+      const int nw = (int)(NPSET * sizeof(Params<T>) / sizeof(uint4));
+      const long long need = std::max<long long>(std::max<long long>(nw, 2 * st), nz);
+      const int nblk = (int)std::min<long long>((need + 255) / 256, 4096);
+      hipLaunchKernelGGL(k_begin_eval, dim3(nblk), dim3(256), 0, stream, static_cast<const uint4*>(h_par_dev),
+                         reinterpret_cast<uint4*>(d_par.p), nw, sums.p, 2 * st, reinterpret_cast<uint4*>(zarena.p), nz);
+      HIPCHECK(hipGetLastError());
+      head_done = true;
+    } else {
+      build_params(lt, ldp, ldm);
+      HIPCHECK(hipMemsetAsync(sums.p, 0, 2 * st * sizeof(double), stream));
+    }
     for (Batch& b : batches) {
       const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
       const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
@@ -1022,11 +1133,12 @@ struct Engine : EngineBase {
       GJ.p = zarena.p;
       DJ.p = GJ.p + up4(3 * gjs);
       Abuf.p = DJ.p + up4(3ll * nJ * N);
-      if (grad && nJ) zero(zarena.p, zarena_elems(nJ, b.asize, N));
-      prep(b.d_dJ.p, nJ, tabJ.p);                          // (first: the head of the critical chain)
+      if (grad && nJ && !(head_done && &b == &batches.front())) zero(zarena.p, zarena_elems(nJ, b.asize, N));
+      prep(b.d_dJ.p, nJ, tabJ.p, true);                    // (first: the head of the critical chain)
       // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
-      // start now on a side stream, next to the joint forward solve; the assembly waits for them
-      if (fused_small) small_classes(b, 0, grad);
+      // run on a side stream from here on, next to the joint forward solve (whose launch is issued first - it is the
+      // critical chain); the assembly waits for them
+      if (fused_small) small_fork(0);
       if (!fused_small) prep(b.d_dS.p, nS, tabS.p);        // (k_spatient builds its own tables in LDS)
       const bool per_patient = !use_jacobi && nJ >= psolve_min;
       // the tile-level substitution solver skips dead tiles and its consumers read them: those parts of pi / q_J
@@ -1048,6 +1160,7 @@ struct Engine : EngineBase {
       if (use_jacobi) launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
       if (per_patient) psolve(false, b, pi.p, 2);
       else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
+      if (fused_small) small_classes(b, 0, grad);
       // 3 marginal right-hand sides
       if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ) {
@@ -1094,7 +1207,7 @@ struct Engine : EngineBase {
             // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
             const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
             timed(MMHN_K_PCLASS, mbytes, [&]() {
-              hipLaunchKernelGGL((k_pclass<T>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
+              hipLaunchKernelGGL((k_pclass<T>), dim3(nJ, nJ <= prep_split_max ? 2 : 1), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
                                  pi.p, qJ.p, Abuf.p);
             });
             if (!b.mapX.empty())
@@ -1124,7 +1237,13 @@ struct Engine : EngineBase {
         const dim3 cols((nelem + BLOCK - 1) / BLOCK);
         hipLaunchKernelGGL(k_reduce_rows, dim3(cols.x, nchunk), dim3(BLOCK), 0, stream, b.d_pats.p, npat, per, out.p, st, nelem, redbuf.p);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_reduce_parts, dim3(cols.x, 2), dim3(BLOCK), 0, stream, redbuf.p, st, nelem, nchunk, sums.p);
+        if (pack_mode && &b == &batches.back()) {
+          hipLaunchKernelGGL(k_reduce_parts_pack, dim3((st + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, redbuf.p, st, nelem, nchunk,
+                             sums.p, pack_mode, N, pack_a, pack_b, pack_dst);
+          packed_in_eval = true;
+        } else {
+          hipLaunchKernelGGL(k_reduce_parts, dim3(cols.x, 2), dim3(BLOCK), 0, stream, redbuf.p, st, nelem, nchunk, sums.p);
+        }
         HIPCHECK(hipGetLastError());
       }
       if (host_out) {
@@ -1158,6 +1277,11 @@ struct Engine : EngineBase {
   // regularized_optimization.py:296) runs next to the GPU; end: wait and copy out.
   bool sums_pending = false;
   std::chrono::steady_clock::time_point sums_t0, sums_issued;
+  // set by cohort_sums_begin around evaluate(): the last batch's reduction also packs (k_reduce_parts_pack)
+  int pack_mode = 0;
+  double pack_a = 0, pack_b = 0;
+  double* pack_dst = nullptr;
+  bool packed_in_eval = false;
   // w_combined (optional): pack w * EM + NM on the device (k_pack_wsums) - 1 + N^2 + 2N doubles travel instead of
   // 4 + 2 N^2 + 3 N
   int sums_len = 0;                                           // doubles of the pending result
@@ -1167,13 +1291,25 @@ struct Engine : EngineBase {
     const int full = 4 + 2 * N * N + 3 * N;
     const int total = w_combined ? stride() : full;
     abi_sums.alloc(full);
-    if (!h_abi) HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)full * sizeof(double), hipHostMallocDefault));
+    if (!h_abi) {
+      HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abi), (size_t)full * sizeof(double), hipHostMallocDefault));
+      HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_abi_dev), h_abi, 0));
+    }
+    // without a communicator the packing kernel writes the result straight into the pinned buffer; with one the
+    // all-reduce works on device memory and the copy engine brings its result down
+    double* packed = (zero_copy && !comm) ? h_abi_dev : abi_sums.p;
+    pack_mode = w_combined ? 2 : 1;
+    pack_a = w_combined ? *w_combined : (double)n_em; pack_b = (double)n_pat; pack_dst = packed;
+    packed_in_eval = false;
+    struct Unset { int& m; ~Unset() { m = 0; } } unset{pack_mode};
     evaluate(lt, ldp, ldm, grad, nullptr, nullptr);
-    if (w_combined) hipLaunchKernelGGL(k_pack_wsums, dim3(2), dim3(256), 0, stream, sums.p, N, *w_combined, abi_sums.p);
-    else hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, abi_sums.p);
-    HIPCHECK(hipGetLastError());
+    if (!packed_in_eval) {                                 // (no batch: an empty cohort)
+      if (w_combined) hipLaunchKernelGGL(k_pack_wsums, dim3(2), dim3(256), 0, stream, sums.p, N, *w_combined, packed);
+      else hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, packed);
+      HIPCHECK(hipGetLastError());
+    }
     if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
-    HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (packed == abi_sums.p) HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
     sums_issued = std::chrono::steady_clock::now();
     sums_pending = true;
     sums_len = total;

@@ -109,6 +109,10 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
   const int t = k < TB ? k : TB;
   const Params<T>& P = par[d.pset];
   T* out = tab + d.toff;
+  // gridDim.y == 4: the three class tables and the rate tables of a problem are independent - a workgroup each, so
+  // the kernel at the head of every evaluation is one table long (small cohorts); gridDim.y == 1: all in this one
+  const int job = gridDim.y == 1 ? -1 : (int)blockIdx.y;
+  if (job < 0 || job == 3) {
   for (int e = tid; e < k * k; e += BLOCK) {
     const int b = e / k, bb = e % k;
     const int row = d.ev[b], c = d.cls[b];
@@ -129,12 +133,14 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     out[k * k + e] = v;
     out[k * k + k * 64 + e] = u;
   }
-  if (d.mode != JOINT || d.seedbit < 0) return;
+  }
+  if (d.mode != JOINT || d.seedbit < 0 || job == 3) return;
   const int N = d.N, n = N - 1;
   T* o = out + rate_table_size(k);
   for (int c = 0; c < 3; ++c) {                 // 0: dP, 1: dM, 2: dE
     const uint32_t cm = c == 0 ? d.maskP : c == 1 ? d.maskM : d.pairP;
     const int kc = __popc(cm);
+    if (job >= 0 && c != job) { o += 1ll << kc; continue; }
     __syncthreads();
     // th[i][l] = theta[i][event of the l-th class bit]
     for (int e = tid; e < N * kc; e += BLOCK) {
@@ -155,22 +161,23 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     // prod_{l in S} th[i][l] split over three 6-bit parts of S: three table reads per (i, S) instead of kc
     // conditional multiplies (kc <= 18; longer lattices keep the loop)
     const bool split = kc <= 18;
+    const int np6 = kc <= 6 ? 1 : kc <= 12 ? 2 : 3;      // 6-bit parts in use (the others are never read)
     if (split) {
-      for (int e = tid; e < (N + 1) * 192; e += BLOCK) {
-        const int i = e / 192, part = (e % 192) >> 6, v = e & 63;
+      for (int e = tid; e < (N + 1) * np6 * 64; e += BLOCK) {
+        const int i = e / (np6 * 64), part = (e % (np6 * 64)) >> 6, v = e & 63;
         T r = 1;
         for (int l = 0; l < 6; ++l) {
           const int ll = part * 6 + l;
           if (ll < kc && ((v >> l) & 1)) r *= thc[i * kc + ll];
         }
-        rsplit[e] = r;
+        rsplit[i * 192 + part * 64 + v] = r;
       }
       __syncthreads();
     }
     for (long long S = tid; S < (1ll << kc); S += BLOCK) {
       const int s0 = (int)(S & 63), s1 = (int)((S >> 6) & 63), s2 = (int)(S >> 12);
       T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
-      if (split) obs *= rsplit[N * 192 + s0] * rsplit[N * 192 + 64 + s1] * rsplit[N * 192 + 128 + s2];
+      if (split) { T m = rsplit[N * 192 + s0]; if (np6 > 1) m *= rsplit[N * 192 + 64 + s1]; if (np6 > 2) m *= rsplit[N * 192 + 128 + s2]; obs *= m; }
       else for (int l = 0; l < kc; ++l) if ((S >> l) & 1) obs *= thc[N * kc + l];
       T tot = obs;
       const int rows = c == 2 ? N : n;          // the eq block also carries the seeding rate (row n)
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
           if ((S >> l) & 1) continue;
         }
         T r = c == 1 ? P.baseM[i] : P.baseP[i];
-        if (split) r *= rsplit[i * 192 + s0] * rsplit[i * 192 + 64 + s1] * rsplit[i * 192 + 128 + s2];
+        if (split) { T m = rsplit[i * 192 + s0]; if (np6 > 1) m *= rsplit[i * 192 + 64 + s1]; if (np6 > 2) m *= rsplit[i * 192 + 128 + s2]; r *= m; }
         else for (int l = 0; l < kc; ++l) if ((S >> l) & 1) r *= thc[i * kc + l];
         tot += r;
       }
@@ -2452,7 +2459,8 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   constexpr int NST = (1 << TB) / CMB;
   constexpr int NROW = (1 << TB) / 64 / NWV;              // rows per wave of a full tile
   const int kP = __popc(maskP);
-  for (int c = 0; c < 2; ++c) {
+  // gridDim.y == 2: a workgroup per class pass (short launches: their length is one workgroup's chain)
+  for (int c = gridDim.y == 2 ? (int)blockIdx.y : 0; c < (gridDim.y == 2 ? (int)blockIdx.y + 1 : 2); ++c) {
     const uint32_t cmask = c == 0 ? maskP : maskM;
     const uint32_t other = allbits & ~cmask;
     const int kc = __popc(cmask), kf = __popc(other);
@@ -2597,6 +2605,64 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// wave-wide sum with DPP moves only (VALU; the shuffle form of wave_sum is twelve dependent LDS-pipe permutes per
+// fp64 value): quad, half-row and row mirrors, then the gfx9 row broadcasts; the total lands in lane 63
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ double lane63(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v = dpp_add<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);         // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);         // row_mirror: every lane of a 16-lane row holds the row's sum
+  v = dpp_add<0x142, 0xA>(v);         // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);         // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+  return lane63(v);
+}
+// stage S of that reduction (it pairs the lanes that differ in bit S of the lane index)
+template <int S, typename T>
+__device__ __forceinline__ T dpp_stage(T v) {
+  if constexpr (S == 0) return dpp_add<0xB1, 0xF>(v);
+  else if constexpr (S == 1) return dpp_add<0x4E, 0xF>(v);
+  else if constexpr (S == 2) return dpp_add<0x141, 0xF>(v);
+  else if constexpr (S == 3) return dpp_add<0x140, 0xF>(v);
+  else if constexpr (S == 4) return dpp_add<0x142, 0xA>(v);
+  else return dpp_add<0x143, 0xC>(v);
+}
+template <int S, typename T>
+__device__ __forceinline__ T dpp_stages_from(T v) {
+  if constexpr (S < 6) return dpp_stages_from<S + 1>(dpp_stage<S>(v));
+  else return v;
+}
+// total = sum over the lanes of v, M[l] = sum over the lanes whose index has bit l (l < nb; the others are left alone).
+// The masked sums share the stages below their bit with the total: after stages 0 .. l-1 a lane holds the sum of its
+// group of 2^l lanes, the groups with bit l clear are dropped there, and stages l .. 5 finish - 27 stages for the seven
+// sums instead of 42.
+template <typename T>
+__device__ __forceinline__ void wave_bit_sums(T v, int lane, int nb, T& total, T (&M)[6]) {
+  const T p0 = v;
+  const T p1 = dpp_stage<0>(p0), p2 = dpp_stage<1>(p1), p3 = dpp_stage<2>(p2), p4 = dpp_stage<3>(p3), p5 = dpp_stage<4>(p4);
+  total = lane63(dpp_stage<5>(p5));
+  if (nb > 0) M[0] = lane63(dpp_stages_from<0>((lane & 1) ? p0 : T(0)));
+  if (nb > 1) M[1] = lane63(dpp_stages_from<1>((lane & 2) ? p1 : T(0)));
+  if (nb > 2) M[2] = lane63(dpp_stages_from<2>((lane & 4) ? p2 : T(0)));
+  if (nb > 3) M[3] = lane63(dpp_stages_from<3>((lane & 8) ? p3 : T(0)));
+  if (nb > 4) M[4] = lane63(dpp_stages_from<4>((lane & 16) ? p4 : T(0)));
+  if (nb > 5) M[5] = lane63(dpp_stages_from<5>((lane & 32) ? p5 : T(0)));
+}
+
 // grid = (work list of (problem, subset chunk), ceil(N / WAVES)); wave w owns event i = blockIdx.y * WAVES + w
 // and strides the subsets S across its lanes; all reductions are wave-level.
 constexpr int GR_CHUNK = 11;                      // subsets per workgroup of k_grad_rows: 2^11
@@ -2717,14 +2783,17 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
         for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
       }
     }
-    const T total = wave_sum(tot);
+    T total, ML[6];
+    wave_bit_sums(tot, lane, klo, total, ML);
     if (lane == 0) {
       if (drow) { if (kind != GK_E) rb[n] = total; }
       else { rb[i] = total; if (kind == GK_M) rb[n] = total; }
     }
-    for (int l = 0; l < kin; ++l) {
-      const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
-      const T m = wave_sum(v);
+#pragma unroll
+    for (int l = 0; l < 6; ++l)
+      if (l < klo && lane == 0 && lev[l] != i) rb[lev[l]] = ML[l];
+    for (int l = klo; l < kin; ++l) {
+      const T m = wave_sum_dpp(ha[(l - klo) * 64 + lane]);
       if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
     }
     // bits at or above the chunk size are the same for every subset of the chunk

@@ -18,33 +18,6 @@ namespace mmhn {
 // Patients are dealt to four size classes by the largest of their single-tumour spaces (k <= 4, <= 6, <= 9, <= TB): a class is
 // one launch with the LDS its largest space needs, so that the thousands of tiny patients of a real cohort do not pay
 // for the few large ones (a wave per patient for k <= 6, 4 or 16 waves otherwise).
-// wave-wide sum with DPP moves only (VALU; the shuffle form of wave_sum is twelve dependent LDS-pipe permutes per
-// fp64 value): quad, half-row and row mirrors, then the gfx9 row broadcasts; the total lands in lane 63
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_add(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
-  return v + __hiloint2double(hi, lo);
-}
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xF, false));
-}
-__device__ __forceinline__ double lane63(double v) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
-template <typename T>
-__device__ __forceinline__ T wave_sum_dpp(T v) {
-  v = dpp_add<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);         // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);         // row_mirror: every lane of a 16-lane row holds the row's sum
-  v = dpp_add<0x142, 0xA>(v);         // row_bcast15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);         // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
-  return lane63(v);
-}
-
 constexpr int SP_NCLASS = 3;
 constexpr int SP_PPB0 = 4;                    // patients (waves) per workgroup of the one-wave class
 __host__ __device__ inline int spatient_class_maxk(int c) { return c == 0 ? 6 : c == 1 ? 9 : TB; }
@@ -62,7 +35,12 @@ __host__ __device__ inline size_t spatient_lds(int N, int maxk) {
 
 // SPB threads work on one patient; PPB patients share a workgroup (PPB > 1 only with SPB = 64: a wave per patient, no
 // workgroup barrier anywhere - thousands of one-wave workgroups are bound by the dispatcher, ~25 workgroups / us)
-template <typename T, int SPB, int PPB>
+// PAIR (paired rows with BOTH marginal problems, order unknown - likelihood.py:516-620): the two problems are
+// independent but for the sum of their scores, so each gets its own SPB threads and its own LDS slot (PPB slots, two per
+// patient) and they run side by side: one table setup per problem instead of two, no parking of the second forward
+// solution, and the chain of the patient is one problem long.  The scores meet in LDS behind one workgroup barrier.
+// With SPB > 64 the two halves share every barrier, so both walk max(k0, k1) + 1 levels.
+template <typename T, int SPB, int PPB, bool PAIR = false>
 __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int npl, const PatRec* __restrict__ pats, const Desc* __restrict__ dS,
                                               const Params<T>* __restrict__ par,
                                               const uint16_t* __restrict__ perm, const int* __restrict__ lvl,
@@ -70,10 +48,14 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
                                               T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots,
                                               double* __restrict__ lp, int maxk, int N, int with_grad, int block) {
   constexpr int SPW = SPB / 64;
-  static_assert(PPB == 1 || SPB == 64, "several patients per workgroup: one wave each");
+  static_assert(PAIR ? (PPB == 2 || (SPB == 64 && PPB % 2 == 0)) : (PPB == 1 || SPB == 64),
+                "several patients per workgroup: one wave each; a pair of problems: two slots");
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int pslot = PPB == 1 ? 0 : (int)(threadIdx.x / SPB);
-  unsigned char* smem = smem_all + (size_t)pslot * ((spatient_lds<T>(N, maxk) + 15) / 16 * 16);
+  const size_t slot_bytes = (spatient_lds<T>(N, maxk) + 15) / 16 * 16;
+  unsigned char* smem = smem_all + (size_t)pslot * slot_bytes;
+  T* xch = reinterpret_cast<T*>(smem_all + (size_t)PPB * slot_bytes);      // PAIR: the scores of the slots
+  const int mypart = pslot & 1;                                            // PAIR: the problem of this slot
   // synchronisation among the threads of ONE patient
   auto sync = [&]() {
     if (SPB == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -101,12 +83,15 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
   // (its offsets are 64-bit: for T = float an odd number of elements would put it on a 4-byte boundary)
   Desc& dsh = *reinterpret_cast<Desc*>((reinterpret_cast<uintptr_t>(loff + TB + 2) + 7u) & ~(uintptr_t)7u);
   uint16_t* pml = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(&dsh) + DESC_PAD);   // states by popcount
-  const int pidx = block * PPB + pslot;
-  if (pidx >= npl) return;
+  const int pidx = PAIR ? block * (PPB / 2) + (pslot >> 1) : block * PPB + pslot;
+  // (PAIR, one wave per problem: every wave of the workgroup meets the one workgroup barrier of the score exchange)
+  if (pidx >= npl) { if (PAIR && SPB == 64) __syncthreads(); return; }
   const int pat = plist[pidx];
   const PatRec pr = pats[pat];
   const int ps0 = pr.s[0], ps1 = pr.s[1];                  // (no runtime index into the record: it would live in scratch)
-  if (pr.kind == 4 || (ps0 < 0 && ps1 < 0)) return;
+  if (pr.kind == 4 || (PAIR ? (ps0 < 0 || ps1 < 0) : (ps0 < 0 && ps1 < 0))) { if (PAIR && SPB == 64) __syncthreads(); return; }
+  // levels both halves of a PAIR workgroup walk (their barriers are shared)
+  const int kwalk = (PAIR && SPB > 64) ? max(dS[ps0].k, dS[ps1].k) : -1;
   const int tid = (int)(threadIdx.x % SPB), lane = tid & 63, w = tid >> 6;
   const int n = N - 1;
 
@@ -169,9 +154,14 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     const T dmn = P.dm[n];
     for (uint32_t x = tid; x < V; x += SPB) {
       const uint32_t lo = x & 63u, ro = x >> 6;
+      uint32_t gone = 0;                                   // events that have happened in x (bitP is the inverse of ev)
+      for (int b = 0; b < k; ++b) if ((x >> b) & 1u) gone |= 1u << lev[b];
       T dq = 0;
-      for (int i = 0; i < N; ++i)
-        if (d.bitP[i] < 0 || !((x >> d.bitP[i]) & 1u)) dq -= Lc[i * LS + lo] * Uc[i * RS + ro];
+#pragma unroll 8
+      for (int i = 0; i < N; ++i) {                        // (branch-free: the table reads of all events go out together)
+        const T r = Lc[i * LS + lo] * Uc[i * RS + ro];
+        dq -= ((gone >> i) & 1u) ? T(0) : r;
+      }
       const bool sbit = d.seedbit >= 0 && ((x >> d.seedbit) & 1u);
       T dob = 1;
       if (d.obs == OBS_MET) dob = sbit ? LB[lo] * UB[ro] * dmn : LA[lo] * UA[ro];
@@ -202,11 +192,12 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
       }
       y[x] = LID[x] * z;
     };
-    for (int s = 0; s <= k; ++s) {
+    const int ns = kwalk >= 0 ? kwalk : k;
+    for (int s = 0; s <= ns; ++s) {
       const int level = tr ? k - s : s;
       if (SPB == 64) {
         if ((uint32_t)tid < V && __popc((uint32_t)tid) == level) state((uint32_t)tid);
-      } else {
+      } else if (s <= k) {
         for (int idx = loff[level] + tid; idx < loff[level + 1]; idx += SPB) state(pml[idx]);
       }
       sync();
@@ -219,21 +210,26 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
   T full_score = 0;
   for (int part = 0; part < 2; ++part) {
     const int sp = part == 0 ? ps0 : ps1;
-    if (sp < 0) continue;
+    if (sp < 0 || (PAIR && part != mypart)) continue;
     setup(dS[sp]);
     STAMP(0);
     const Desc& d = dsh;
     const T* rg = rhsS + d.off;
     const bool own = pr.kind <= 2;                         // the patient's own space: right-hand side e_0
-    const bool stash = part == 1 && ps0 >= 0;              // second part of a two-part patient: solved in Q, parked in pS
+    const bool stash = !PAIR && part == 1 && ps0 >= 0;     // second part of a two-part patient: solved in Q, parked in pS
     T* yv = stash ? Qv : P0;
     solve(d, yv, false, [&](uint32_t x) { return own ? (x == 0 ? e0_scale<T>() : T(0)) : rg[x]; });
     full_score += yv[(1u << d.k) - 1u];
     if (stash) for (uint32_t x = tid; x < (1u << d.k); x += SPB) pS[d.off + x] = yv[x];
     STAMP(1);
   }
+  if (PAIR) {                                              // score of part 0 + score of part 1, in that order
+    if (tid == 0) xch[pslot] = full_score;
+    __syncthreads();
+    full_score = xch[pslot & ~1] + xch[pslot | 1];
+  }
   const T seed = T(1) / full_score;
-  if (tid == 0) {
+  if (tid == 0 && !(PAIR && mypart == 1)) {
     double l = log((double)full_score) - log((double)e0_scale<T>());
     if (pr.kind == 2) {                                    // likelihood.py:438
       const Desc& d = dsh;                                 // an MT-only row has one problem: still staged
@@ -251,14 +247,14 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
   const int nparts = (ps0 >= 0) + (ps1 >= 0);
   for (int part = 0; part < 2; ++part) {
     const int sp = part == 0 ? ps0 : ps1;
-    if (sp < 0) continue;
-    if (nparts == 2) setup(dS[sp]);                        // a lone part's tables (and descriptor) are still in place
+    if (sp < 0 || (PAIR && part != mypart)) continue;
+    if (nparts == 2 && !PAIR) setup(dS[sp]);               // a lone part's tables (and descriptor) are still in place
     const Desc& d = dsh;
     const int k = d.k;
     const uint32_t V = 1u << k, last = V - 1u;
     solve(d, Qv, true, [&](uint32_t x) { return x == last ? seed : T(0); });
     STAMP(3);
-    if (part == 1 && ps0 >= 0) {                           // fetch the parked forward solution (P0 is free now)
+    if (!PAIR && part == 1 && ps0 >= 0) {                  // fetch the parked forward solution (P0 is free now)
       sync();
       for (uint32_t x = tid; x < V; x += SPB) P0[x] = pS[d.off + x];
       sync();
@@ -318,24 +314,43 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     if (SPW == 1) {
       // one wave: lane i owns event i and walks the states.  The state is wave-uniform, so "S contains bit l" is a
       // scalar branch and every G[i][ev(l)] is a private register sum - no cross-lane reduction at all
-      const int i = lane;
+      // (two lanes per event, N <= 32: lane i + 32 h takes the states whose top bit is h - half the walk; the low bits
+      // of the state are the same in both halves, the top bit's column is the upper half's total)
+      const int i = lane & 31, h = lane >> 5;
       const bool rowok = i < N;
       const int slot = rowok ? d.bitP[i] : -1;             // local bit of event i or -1
+      const int kt = k > 0 ? k - 1 : 0;                    // the top bit
+      const uint32_t Vh = k > 0 ? V >> 1 : 1u, hs = h && k > 0 ? Vh : 0u;
       T tot = 0, acc[6];
 #pragma unroll
       for (int l = 0; l < 6; ++l) acc[l] = 0;
-      if (rowok) {
+      if (rowok && !(h && k == 0)) {
         const T ui = Uc[i * RS];
+        const uint32_t sb = slot >= 0 ? 1u << slot : 0u;
 #pragma unroll 4
-        for (uint32_t S = 0; S < V; ++S) {
-          const T pv = p[S];
-          T a = -pv * Qv[S];
-          if (slot >= 0) a += pv * Qv[S | (1u << slot)];
-          const bool blocked = slot >= 0 && ((S >> slot) & 1u);
-          const T f = blocked ? T(0) : Lc[i * LS + S] * ui * a;
+        for (uint32_t Sl = 0; Sl < Vh; ++Sl) {
+          const uint32_t S = Sl | hs;
+          const T pv = p[S], q0 = Qv[S], q1 = Qv[S | sb], lc = Lc[i * LS + S];
+          T a = -pv * q0;
+          if (slot >= 0) a += pv * q1;
+          const T f = (S & sb) ? T(0) : lc * ui * a;
           tot += f;
 #pragma unroll
-          for (int l = 0; l < 6; ++l) if ((S >> l) & 1u) acc[l] += f;       // wave-uniform condition
+          for (int l = 0; l < 5; ++l) if ((Sl >> l) & 1u) acc[l] += f;      // wave-uniform condition
+        }
+      }
+      // the upper half's sums come down
+      const T tup = __shfl_down(tot, 32);
+      T aup[5];
+#pragma unroll
+      for (int l = 0; l < 5; ++l) aup[l] = __shfl_down(acc[l], 32);
+      if (rowok && h == 0) {
+        if (k > 0) {
+#pragma unroll
+          for (int l = 0; l < 5; ++l) acc[l] += aup[l];
+#pragma unroll
+          for (int l = 0; l < 6; ++l) if (l == kt) acc[l] = tup;
+          tot += tup;
         }
         T* row = G + (long long)i * N;
         for (int j = 0; j < N; ++j) row[j] = 0;
@@ -348,29 +363,37 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
       const int klo = k < 6 ? k : 6, nhi = k - klo;
       for (int i = w; i < N; i += SPW) {
         const int slot = d.bitP[i];
+        const uint32_t sb = slot >= 0 ? 1u << slot : 0u;
+        const T lcv = Lc[i * LS + lane];                   // (the lane part of the rate is the same in every chunk)
         T tot = 0, hi[TB - 6];
 #pragma unroll
         for (int l = 0; l < TB - 6; ++l) hi[l] = 0;
-        for (uint32_t S0 = 0; S0 < V; S0 += 64) {
-          const uint32_t S = S0 + (uint32_t)lane;
-          T f = 0;
-          if (S < V && !(slot >= 0 && ((S >> slot) & 1u))) {
-            const T pv = p[S];
-            T a = -pv * Qv[S];
-            if (slot >= 0) a += pv * Qv[S | (1u << slot)];
-            f = Lc[i * LS + (S & 63u)] * Uc[i * RS + (S >> 6)] * a;
-          }
-          tot += f;
+        constexpr int GU = 4;                              // chunks of 64 states in flight (reads first, branch-free)
+        for (uint32_t S00 = 0; S00 < V; S00 += 64 * GU) {
+          T pv[GU], q0[GU], q1[GU], uc[GU];
 #pragma unroll
-          for (int l = 0; l < TB - 6; ++l) if (l < nhi && ((S0 >> (6 + l)) & 1u)) hi[l] += f;
+          for (int u = 0; u < GU; ++u) {
+            const uint32_t S = S00 + 64 * u + (uint32_t)lane, Sc = S < V ? S : 0u;
+            pv[u] = p[Sc]; q0[u] = Qv[Sc]; q1[u] = Qv[Sc | sb]; uc[u] = Uc[i * RS + (Sc >> 6)];
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            const uint32_t S0 = S00 + 64 * u, S = S0 + (uint32_t)lane;
+            T a = -pv[u] * q0[u];
+            if (slot >= 0) a += pv[u] * q1[u];
+            const T f = (S < V && !(S & sb)) ? lcv * uc[u] * a : T(0);
+            tot += f;
+#pragma unroll
+            for (int l = 0; l < TB - 6; ++l) if (l < nhi && ((S0 >> (6 + l)) & 1u)) hi[l] += f;
+          }
         }
-        const T total = wave_sum_dpp(tot);
+        T total, ML[6];
+        wave_bit_sums(tot, lane, klo, total, ML);
         T mine = 0;                                        // lane j keeps G[i][j]
         if (lane == i) mine = total;
-        for (int l = 0; l < klo; ++l) {
-          const T m = wave_sum_dpp(((lane >> l) & 1) ? tot : T(0));
-          if (lane == lev[l] && lev[l] != i) mine = m;
-        }
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+          if (l < klo && lane == lev[l] && lev[l] != i) mine = ML[l];
 #pragma unroll
         for (int h = 0; h < TB - 6; ++h) {                 // static register index (no scratch)
           if (h < nhi) {
@@ -393,20 +416,28 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
 #define SPATIENT_ARGS pats, dS, par, perm, lvl, rhsS, pS, qS, GS, bmS, dots, lp
 
 // one size class per launch (the 1024-thread class)
-template <typename T, int SPB, int PPB>
+template <typename T, int SPB, int PPB, bool PAIR = false>
 __global__ __launch_bounds__(SPB * PPB) void k_spatient(const int* __restrict__ plist, int npl, SPATIENT_PARAMS, int maxk, int N,
                                                         int with_grad) {
-  spatient_body<T, SPB, PPB>(plist, npl, SPATIENT_ARGS, maxk, N, with_grad, (int)blockIdx.x);
+  spatient_body<T, SPB, PPB, PAIR>(plist, npl, SPATIENT_ARGS, maxk, N, with_grad, (int)blockIdx.x);
 }
 
 // the two 256-thread classes in ONE launch - side by side without a second stream: workgroups [0, nb0) take SP_PPB0
 // one-wave patients each (list0, spaces of at most maxk0 bits), the others one patient each (list1, maxk1)
+// pair0 / pair1: the paired rows of the two classes that have both marginal problems (PAIR above: two one-wave patients,
+// or one patient with 128 threads per problem, to a workgroup).  Longest first: the 256-thread classes, then the waves.
 template <typename T>
 __global__ __launch_bounds__(256) void k_spatient2(const int* __restrict__ list0, int n0, int maxk0, const int* __restrict__ list1,
-                                                   int n1, int maxk1, SPATIENT_PARAMS, int N, int with_grad) {
-  const int nb0 = (n0 + SP_PPB0 - 1) / SP_PPB0;
-  if ((int)blockIdx.x < nb0) spatient_body<T, 64, SP_PPB0>(list0, n0, SPATIENT_ARGS, maxk0, N, with_grad, (int)blockIdx.x);
-  else spatient_body<T, 256, 1>(list1, n1, SPATIENT_ARGS, maxk1, N, with_grad, (int)blockIdx.x - nb0);
+                                                   int n1, int maxk1, const int* __restrict__ pair0, int np0,
+                                                   const int* __restrict__ pair1, int np1, SPATIENT_PARAMS, int N, int with_grad) {
+  int b = (int)blockIdx.x;
+  if (b < np1) { spatient_body<T, 128, 2, true>(pair1, np1, SPATIENT_ARGS, maxk1, N, with_grad, b); return; }
+  b -= np1;
+  if (b < n1) { spatient_body<T, 256, 1>(list1, n1, SPATIENT_ARGS, maxk1, N, with_grad, b); return; }
+  b -= n1;
+  const int nbp = (np0 + SP_PPB0 / 2 - 1) / (SP_PPB0 / 2);
+  if (b < nbp) { spatient_body<T, 64, SP_PPB0, true>(pair0, np0, SPATIENT_ARGS, maxk0, N, with_grad, b); return; }
+  spatient_body<T, 64, SP_PPB0>(list0, n0, SPATIENT_ARGS, maxk0, N, with_grad, b - nbp);
 }
 #undef SPATIENT_PARAMS
 #undef SPATIENT_ARGS

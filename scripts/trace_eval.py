@@ -4,7 +4,7 @@
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_pack_sums" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_pack_sums" in r["Kernel_Name"] or "k_reduce_parts_pack" in r["Kernel_Name"]]
 nth = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 a, b = idx[-nth - 1] + 1, idx[-nth] + 1
 t0 = int(rows[a]["Start_Timestamp"])
