@@ -119,18 +119,27 @@ def _cache_key(dat, rank, world):
     return (None, zlib.crc32(arr.tobytes()), arr.shape, "i1", rank, world, _OPTIONS["dtype"])
 
 
+_CRC_ROWS = {}
+
+
 def _sample_crc(dat: np.ndarray) -> int:
-    """Guard of the identity-keyed cache against in-place edits: CRC of up to 64 evenly spaced rows (a few KB, ~2 us
-    per call - the reference is a pure function of `dat`, a full pass per evaluation would cost more than a LUAD-sized
-    evaluation itself).  Catches relabelled / masked / refilled cohorts; a single edited row between the samples still
-    needs invalidate()."""
+    """Guard of the identity-keyed cache against in-place edits: CRC of up to 64 evenly spaced rows (a few KB, ~7 us
+    per call, run while the GPU evaluates - the reference is a pure function of `dat`, a full pass per evaluation
+    would cost more than a LUAD-sized evaluation itself).  Catches relabelled / masked / refilled cohorts; a single
+    edited row between the samples still needs invalidate()."""
     if dat.shape[0] <= 64:
         return zlib.crc32(np.ascontiguousarray(dat).tobytes())
-    idx = np.linspace(0, dat.shape[0] - 1, 64).astype(np.int64)
+    idx = _CRC_ROWS.get(dat.shape[0])
+    if idx is None:
+        if len(_CRC_ROWS) > 64:
+            _CRC_ROWS.clear()
+        idx = _CRC_ROWS[dat.shape[0]] = np.linspace(0, dat.shape[0] - 1, 64).astype(np.int64)
     return zlib.crc32(np.ascontiguousarray(dat[idx]).tobytes())
 
 
-def _engine_for(dat) -> Engine:
+def _engine_for(dat, check: bool = True) -> Engine:
+    """The engine holding `dat`'s layout.  check=False: a cache hit is returned without the in-place-edit guard - the
+    caller runs it next to the GPU (_result(..., guard=dat)) and evaluates again if it fires."""
     import os
     import weakref
     rank, world = _rank_world()
@@ -139,7 +148,7 @@ def _engine_for(dat) -> Engine:
     key = _cache_key(dat, rank, world)
     hit = _CACHE.get(key)
     if hit is not None and (hit[1] is None or hit[1]() is dat):
-        if not isinstance(dat, np.ndarray) or hit[0]._sample_crc == _sample_crc(dat):
+        if not check or not isinstance(dat, np.ndarray) or hit[0]._sample_crc == _sample_crc(dat):
             return hit[0]
         _CACHE.pop(key)[0].close()                            # same array object, edited in place: lay it out again
         hit = None
@@ -175,34 +184,26 @@ def _reduce_mode():
     return os.environ.get("MMHN_REDUCE", "")
 
 
-def _sums(eng: Engine, log_theta, log_d_p, log_d_m, with_grad: bool, meanwhile: Callable = None):
-    """Cohort-wide partial sums: this rank's shard, combined over the ranks by ONE all-reduce - inside the library
-    on the engine's stream (RCCL) when the communicator is attached, else through torch.distributed.
-    `meanwhile()` (host work that does not need the result: the penalty terms) runs while the GPU evaluates;
-    returns (sums, meanwhile's result)."""
-    eng.cohort_sums_begin(log_theta, log_d_p, log_d_m, with_grad=with_grad)
-    try:
-        aside = meanwhile() if meanwhile is not None else None
-    finally:
-        sums = eng.cohort_sums_end()
-    if eng._sharded and not eng._device_comm:
-        sums = _dist.allreduce_sums_fixed_order(sums) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(sums)
-    return sums, aside
-
-
-def _result(eng: Engine, log_theta, log_d_p, log_d_m, perc_met: float, with_grad: bool, meanwhile: Callable = None):
-    """((score, d_theta, d_dp, d_dm), meanwhile's result).  Sharded engines pre-combine EM and NM on the device
-    (the weight only needs the global counts): 1 + N^2 + 2N doubles cross the ranks instead of 4 + 2 N^2 + 3 N."""
-    if not eng._sharded:
-        sums, aside = _sums(eng, log_theta, log_d_p, log_d_m, with_grad, meanwhile)
-        return _dist.combine_sums(sums, eng.N, perc_met), aside
+def _result(eng: Engine, log_theta, log_d_p, log_d_m, perc_met: float, with_grad: bool, meanwhile: Callable = None,
+            guard=None):
+    """((score, d_theta, d_dp, d_dm), meanwhile's result).  EM and NM sums are combined on the device (the weight of
+    regularized_optimization.py:121-128 only needs the global counts, known when the cohort is set): 1 + N^2 + 2N
+    doubles come back - and, with several ranks, cross them in ONE all-reduce, inside the library on the engine's
+    stream (RCCL) when the communicator is attached, else through torch.distributed.
+    `meanwhile()` (host work that does not need the result: the penalty terms) runs while the GPU evaluates, and so
+    does the cache guard of `guard` (the caller's `dat`, engine from _engine_for(dat, check=False)): if the array was
+    edited in place since its layout was built, the result is dropped and the evaluation repeated on a fresh layout."""
     w, n_full = _dist.em_weight(*eng._global_counts, perc_met)
     eng.cohort_wsums_begin(log_theta, log_d_p, log_d_m, w, with_grad=with_grad)
+    stale = False
     try:
-        aside = meanwhile() if meanwhile is not None else None
+        stale = isinstance(guard, np.ndarray) and eng._sample_crc != _sample_crc(guard)
+        aside = meanwhile() if meanwhile is not None and not stale else None
     finally:
         ws = eng.cohort_wsums_end()
-    if not eng._device_comm:
+    if stale:
+        return _result(_engine_for(guard), log_theta, log_d_p, log_d_m, perc_met, with_grad, meanwhile)
+    if eng._sharded and not eng._device_comm:
         ws = _dist.allreduce_sums_fixed_order(ws) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(ws)
     return _dist.split_wsums(ws, eng.N, n_full), aside
 
@@ -250,14 +251,14 @@ def symmetric_penal(params, n_total: int, eps=1e-05):
 
 def score(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """Log-likelihood of the dataset (regularized_optimization.py:55-130)."""
-    eng = _engine_for(dat)
-    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, False)[0][0]
+    eng = _engine_for(dat, check=False)
+    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, False, guard=dat)[0][0]
 
 
 def score_and_grad(log_theta, log_d_p, log_d_m, dat, perc_met: float):
     """(score, d_theta, d_d_p, d_d_m)  (regularized_optimization.py:163-267)."""
-    eng = _engine_for(dat)
-    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, True)[0]
+    eng = _engine_for(dat, check=False)
+    return _result(eng, log_theta, log_d_p, log_d_m, perc_met, True, guard=dat)[0]
 
 
 def _unpack(params, n_total):
@@ -270,8 +271,8 @@ def score_reg(params, dat, perc_met: float, penal: Callable, w_penal: float):
     """regularized_optimization.py:133-160."""
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
-    eng = _engine_for(dat)
-    res, (pen, _) = _result(eng, th, dp, dm, perc_met, False, meanwhile=lambda: penal(params, n_total))    # penalty next to the GPU
+    eng = _engine_for(dat, check=False)
+    res, (pen, _) = _result(eng, th, dp, dm, perc_met, False, meanwhile=lambda: penal(params, n_total), guard=dat)    # penalty next to the GPU
     return np.array(-res[0] + w_penal * pen)
 
 
@@ -279,8 +280,8 @@ def score_and_grad_reg(params, dat, perc_met: float, penal: Callable, w_penal: f
     """regularized_optimization.py:270-298."""
     n_total = (np.asarray(dat).shape[1] - 3) // 2 + 1
     th, dp, dm = _unpack(params, n_total)
-    eng = _engine_for(dat)
-    (sc, d_th, d_d_p, d_d_m), (pen, pen_) = _result(eng, th, dp, dm, perc_met, True, meanwhile=lambda: penal(params, n_total))  # penalty next to the GPU
+    eng = _engine_for(dat, check=False)
+    (sc, d_th, d_d_p, d_d_m), (pen, pen_) = _result(eng, th, dp, dm, perc_met, True, meanwhile=lambda: penal(params, n_total), guard=dat)  # penalty next to the GPU
     grad_vec = np.concatenate((d_th.flatten(), d_d_p, d_d_m))
     return np.array(-sc + w_penal * pen), -grad_vec + w_penal * pen_
 

@@ -175,6 +175,29 @@ def test_synthetic_cohort_against_oracle():
     np.testing.assert_allclose(gdm, b2, rtol=RTOL, atol=1e-9)
 
 
+def test_cohort_edited_in_place_is_evaluated_afresh():
+    """The reference's objective is a pure function of `dat`; ours keeps the cohort's layout in HBM keyed by the array's
+    identity.  The guard against in-place edits runs next to the GPU (regularized_optimization._result): an edited
+    array gives the edited cohort's value, at once and on the following call."""
+    from metmhn_amd import synthetic
+    import metmhn_amd.regularized_optimization as ro
+    n = 6
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.mixed_cohort(n, 200, seed=11)
+    edited = dat.copy()
+    edited[:, -3] = 0                                       # every row: no metastasis observed ...
+    edited[:, 1:2 * n:2] = 0
+    edited[:, -1] = 0                                       # ... type 0
+    want_before, want_after = ro.score(lt, dp, dm, dat.copy(), 0.3), ro.score(lt, dp, dm, edited, 0.3)
+    assert abs(want_before - want_after) > 1e-3
+    work = dat.copy()
+    assert ro.score(lt, dp, dm, work, 0.3) == want_before
+    work[:] = edited                                        # same array object, new contents
+    assert ro.score(lt, dp, dm, work, 0.3) == want_after
+    s, *_ = ro.score_and_grad(lt, dp, dm, work, 0.3)
+    assert abs(s - want_after) <= 1e-12 * abs(want_after)
+
+
 def test_random_patients_against_c_oracle(monkeypatch):
     """Randomised sweep: n = 1..9 events, every type / order code (incl. -99 and invalid order values on paired
     rows), dense and sparse genotypes, empty and full rows; per-patient log-prob and gradients from both kernel
