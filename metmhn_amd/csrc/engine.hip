@@ -477,7 +477,8 @@ struct Engine : EngineBase {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_rows<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pclass<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pclass<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_class_marg<T>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
@@ -539,7 +540,8 @@ struct Engine : EngineBase {
   // enough for its length to be one workgroup's chain; large cohorts keep one workgroup per problem
   void prep(const Desc* descs, int nprob, T* tab, bool joint = false) {
     if (nprob == 0) return;
-    hipLaunchKernelGGL((k_prep<T>), dim3(nprob, joint && nprob <= prep_split_max ? 4 : 1), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
   }
 
@@ -1110,14 +1112,18 @@ struct Engine : EngineBase {
     if (zero_copy && !batches.empty()) {
       build_params(lt, ldp, ldm, false);
       const Batch& b0 = batches.front();
-      const long long nz = grad && !b0.dJ.empty() ? zarena_elems((long long)b0.dJ.size(), b0.asize, N) * (long long)sizeof(T) / 16 : 0;
+      // (a large batch clears its ~GB of work arrays with the runtime's fill, which is faster at that size: +1.0 ms
+      // per evaluation on the 5 000-patient bench cohort when this kernel did it)
+      long long nz = grad && !b0.dJ.empty() ? zarena_elems((long long)b0.dJ.size(), b0.asize, N) * (long long)sizeof(T) / 16 : 0;
+      const bool fill_here = nz <= (32ll << 20) / 16;
+      if (!fill_here) nz = 0;
       const int nw = (int)(NPSET * sizeof(Params<T>) / sizeof(uint4));
       const long long need = std::max<long long>(std::max<long long>(nw, 2 * st), nz);
       const int nblk = (int)std::min<long long>((need + 255) / 256, 4096);
       hipLaunchKernelGGL(k_begin_eval, dim3(nblk), dim3(256), 0, stream, static_cast<const uint4*>(h_par_dev),
                          reinterpret_cast<uint4*>(d_par.p), nw, sums.p, 2 * st, reinterpret_cast<uint4*>(zarena.p), nz);
       HIPCHECK(hipGetLastError());
-      head_done = true;
+      head_done = fill_here;
     } else {
       build_params(lt, ldp, ldm);
       HIPCHECK(hipMemsetAsync(sums.p, 0, 2 * st * sizeof(double), stream));
@@ -1207,8 +1213,10 @@ struct Engine : EngineBase {
             // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
             const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
             timed(MMHN_K_PCLASS, mbytes, [&]() {
-              hipLaunchKernelGGL((k_pclass<T>), dim3(nJ, nJ <= prep_split_max ? 2 : 1), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p,
-                                 pi.p, qJ.p, Abuf.p);
+              if (nJ <= prep_split_max)
+                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 2), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+              else
+                hipLaunchKernelGGL((k_pclass<T, false>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
             });
             if (!b.mapX.empty())
               hipLaunchKernelGGL((k_class_marg<T>), dim3((unsigned)b.mapX.size()), dim3(CMB), 2 * sizeof(T) << TB, stream,

@@ -97,7 +97,7 @@ __host__ __device__ inline long long table_size(const Desc& d) {
   return s;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
                                                 const Params<T>* __restrict__ par, T* tab) {
   __shared__ T thc[(MAXN + 1) * MAXN];  // later reused as th[i][class bit l]
@@ -109,9 +109,9 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
   const int t = k < TB ? k : TB;
   const Params<T>& P = par[d.pset];
   T* out = tab + d.toff;
-  // gridDim.y == 4: the three class tables and the rate tables of a problem are independent - a workgroup each, so
-  // the kernel at the head of every evaluation is one table long (small cohorts); gridDim.y == 1: all in this one
-  const int job = gridDim.y == 1 ? -1 : (int)blockIdx.y;
+  // SPLIT (gridDim.y == 4): the three class tables and the rate tables of a problem are independent - a workgroup
+  // each, so the kernel at the head of every evaluation is one table long (small cohorts); else all in this one
+  const int job = SPLIT ? (int)blockIdx.y : -1;
   if (job < 0 || job == 3) {
   for (int e = tid; e < k * k; e += BLOCK) {
     const int b = e / k, bb = e % k;
@@ -161,16 +161,17 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     // prod_{l in S} th[i][l] split over three 6-bit parts of S: three table reads per (i, S) instead of kc
     // conditional multiplies (kc <= 18; longer lattices keep the loop)
     const bool split = kc <= 18;
-    const int np6 = kc <= 6 ? 1 : kc <= 12 ? 2 : 3;      // 6-bit parts in use (the others are never read)
+    const int np6 = !SPLIT ? 3 : kc <= 6 ? 1 : kc <= 12 ? 2 : 3;   // 6-bit parts in use (SPLIT: the others are left out)
     if (split) {
-      for (int e = tid; e < (N + 1) * np6 * 64; e += BLOCK) {
-        const int i = e / (np6 * 64), part = (e % (np6 * 64)) >> 6, v = e & 63;
+      for (int e = tid; e < (N + 1) * 192; e += BLOCK) {
+        const int i = e / 192, part = (e % 192) >> 6, v = e & 63;
+        if (part >= np6) continue;
         T r = 1;
         for (int l = 0; l < 6; ++l) {
           const int ll = part * 6 + l;
           if (ll < kc && ((v >> l) & 1)) r *= thc[i * kc + ll];
         }
-        rsplit[i * 192 + part * 64 + v] = r;
+        rsplit[e] = r;
       }
       __syncthreads();
     }
@@ -2438,7 +2439,7 @@ __device__ __forceinline__ uint32_t low_bits(uint32_t m, int n) {
   return r;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, const T* __restrict__ p,
                                                    const T* __restrict__ q, T* A) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2459,8 +2460,8 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   constexpr int NST = (1 << TB) / CMB;
   constexpr int NROW = (1 << TB) / 64 / NWV;              // rows per wave of a full tile
   const int kP = __popc(maskP);
-  // gridDim.y == 2: a workgroup per class pass (short launches: their length is one workgroup's chain)
-  for (int c = gridDim.y == 2 ? (int)blockIdx.y : 0; c < (gridDim.y == 2 ? (int)blockIdx.y + 1 : 2); ++c) {
+  // SPLIT (gridDim.y == 2): a workgroup per class pass (short launches: their length is one workgroup's chain)
+  for (int c = SPLIT ? (int)blockIdx.y : 0; c < (SPLIT ? (int)blockIdx.y + 1 : 2); ++c) {
     const uint32_t cmask = c == 0 ? maskP : maskM;
     const uint32_t other = allbits & ~cmask;
     const int kc = __popc(cmask), kf = __popc(other);
@@ -2783,17 +2784,14 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
         for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
       }
     }
-    T total, ML[6];
-    wave_bit_sums(tot, lane, klo, total, ML);
+    const T total = wave_sum(tot);
     if (lane == 0) {
       if (drow) { if (kind != GK_E) rb[n] = total; }
       else { rb[i] = total; if (kind == GK_M) rb[n] = total; }
     }
-#pragma unroll
-    for (int l = 0; l < 6; ++l)
-      if (l < klo && lane == 0 && lev[l] != i) rb[lev[l]] = ML[l];
-    for (int l = klo; l < kin; ++l) {
-      const T m = wave_sum_dpp(ha[(l - klo) * 64 + lane]);
+    for (int l = 0; l < kin; ++l) {
+      const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
+      const T m = wave_sum(v);
       if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
     }
     // bits at or above the chunk size are the same for every subset of the chunk

@@ -46,7 +46,7 @@ def main():
            "source": {"git_head": head, "csrc_sha16": csrc_sha16()}}
     ef, ew = per_launch("eval_f", "FETCH_SIZE"), per_launch("eval_w", "WRITE_SIZE")
     ek = {}
-    for name, prefix in (("psolve_fwd", "k_psolve2<double, false"), ("psolve_adj", "k_psolve2<double, true"), ("pclass", "k_pclass<double>")):
+    for name, prefix in (("psolve_fwd", "k_psolve2<double, false"), ("psolve_adj", "k_psolve2<double, true"), ("pclass", "k_pclass<double")):
         kern = next((kname for kname in ef if kname.startswith(prefix)), None)      # (any DLOK instantiation)
         if kern is None:
             continue
