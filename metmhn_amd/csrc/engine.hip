@@ -1075,7 +1075,7 @@ struct Engine : EngineBase {
       HIPCHECK(hipStreamWaitEvent(sd, ev_fork[which], 0));
     }
     fork_recorded[which] = false;
-#define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, rhsS.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
+#define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, b.d_dJ.p, pi.p, links.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
     auto big_class = [&]() {
       if (!n2) return;
       const size_t lds = (spatient_lds<T>(N, mk2) + 15) / 16 * 16;
@@ -1169,7 +1169,7 @@ struct Engine : EngineBase {
       if (fused_small) small_classes(b, 0, grad);
       // 3 marginal right-hand sides
       if (!fused_small) zero(rhsS.p, b.vecS);
-      if (nJ) {
+      if (nJ && !fused_small) {                           // (the small-space kernels read pi themselves and write the links)
         hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.paired.size(), 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
                            b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_paired.p);
         HIPCHECK(hipGetLastError());
@@ -1214,7 +1214,7 @@ struct Engine : EngineBase {
             const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
             timed(MMHN_K_PCLASS, mbytes, [&]() {
               if (nJ <= prep_split_max)
-                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 2), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 3), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
               else
                 hipLaunchKernelGGL((k_pclass<T, false>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
             });
@@ -1226,10 +1226,12 @@ struct Engine : EngineBase {
                                b.d_mapJ.p, pi.p, qJ.p, Abuf.p);
           }
           HIPCHECK(hipGetLastError());
-          // (its own launch: folded into k_pclass it cost more than the launch - k_pclass 20.5 -> 21.9 ms on the bench
-          // cohort, the LUAD evaluation +25 us)
-          hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
-          HIPCHECK(hipGetLastError());
+          // (its own launch: folded into the workgroups of k_pclass it cost more than the launch - k_pclass 20.5 -> 21.9 ms
+          // on the bench cohort, the LUAD evaluation +25 us; short launches run it as workgroups of their own in k_pclass)
+          if (!(per_patient && nJ <= prep_split_max)) {
+            hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+            HIPCHECK(hipGetLastError());
+          }
           launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p, -1, b.d_grcJ, DJ.p, gjs);
         }
         // 7 assembly

@@ -2446,6 +2446,9 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   T* pt = reinterpret_cast<T*>(smem);
   T* qt = pt + (1 << TB) + PC_PAD * 64;                  // + 2^(PCA-1) slack behind it for the neighbour reads
   const Desc& d = dJ[blockIdx.x];
+  // SPLIT (gridDim.y == 3): a workgroup per class pass and one for the eq block's flows (k_eq_flows) - short launches,
+  // whose length is one workgroup's chain
+  if (SPLIT && blockIdx.y == 2) { eq_flows_body(d, p, q, A, (int)threadIdx.x, CMB); return; }
   const int seedbit = d.seedbit;
   if (seedbit < 0) return;
   const int k = d.k;
@@ -2460,7 +2463,6 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   constexpr int NST = (1 << TB) / CMB;
   constexpr int NROW = (1 << TB) / 64 / NWV;              // rows per wave of a full tile
   const int kP = __popc(maskP);
-  // SPLIT (gridDim.y == 2): a workgroup per class pass (short launches: their length is one workgroup's chain)
   for (int c = SPLIT ? (int)blockIdx.y : 0; c < (SPLIT ? (int)blockIdx.y + 1 : 2); ++c) {
     const uint32_t cmask = c == 0 ? maskP : maskM;
     const uint32_t other = allbits & ~cmask;

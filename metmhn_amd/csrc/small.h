@@ -44,7 +44,8 @@ template <typename T, int SPB, int PPB, bool PAIR = false>
 __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int npl, const PatRec* __restrict__ pats, const Desc* __restrict__ dS,
                                               const Params<T>* __restrict__ par,
                                               const uint16_t* __restrict__ perm, const int* __restrict__ lvl,
-                                              const T* __restrict__ rhsS, T* __restrict__ pS, T* __restrict__ qS,
+                                              const Desc* __restrict__ dJ, const T* __restrict__ pi, JLink<T>* __restrict__ links,
+                                              T* __restrict__ pS, T* __restrict__ qS,
                                               T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots,
                                               double* __restrict__ lp, int maxk, int N, int with_grad, int block) {
   constexpr int SPW = SPB / 64;
@@ -204,6 +205,38 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     }
   };
 
+  // paired rows: the right-hand side of a marginal problem is [0 ; D * pi[compatible states]] (k_gather_marg, likelihood.py
+  // :573-575, :617-618) - taken straight from the joint solution, no launch and no buffer in between; D is constant on
+  // those states (obs_const: same factors in the same order) and is also the constant of the joint adjoint's
+  // right-hand side, so the links are written here
+  struct Marg { T c; uint32_t fixed, free_, half; long long joff; };
+  auto marg_of = [&](int part, int k) -> Marg {
+    const Desc* dj = dJ + pr.j;
+    const Params<T>& PT = par[PS_THETA];
+    const int kj = dj->k;
+    sync();
+    if (tid < 32) {
+      T f = 1;
+      if (tid < kj && dj->cls[tid] == (part == 0 ? CP : CM)) f = part == 0 ? PT.dp[dj->ev[tid]] : PT.dm[dj->ev[tid]];
+      red[tid] = f;
+    }
+    sync();
+    T c = part == 0 ? PT.dp[N - 1] : PT.dm[N - 1];
+    for (int b = 0; b < kj; ++b) c *= red[b];
+    sync();
+    Marg m;
+    m.c = c;
+    m.fixed = (part == 0 ? dj->maskP : dj->maskM) | (1u << dj->seedbit);
+    m.free_ = part == 0 ? dj->maskM : dj->maskP;
+    m.half = 1u << (k - 1);
+    m.joff = dj->off;
+    return m;
+  };
+  auto marg_rhs = [&](const Marg& m, uint32_t x) -> T {
+    return x < m.half ? T(0) : m.c * pi[m.joff + (pdep32(x - m.half, m.free_) | m.fixed)];
+  };
+  Marg mg0{}, mg1{};
+
   // ---- forward solves of the patient's problems
   STAMP_DECL;
   STAMP_START;
@@ -214,14 +247,23 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     setup(dS[sp]);
     STAMP(0);
     const Desc& d = dsh;
-    const T* rg = rhsS + d.off;
     const bool own = pr.kind <= 2;                         // the patient's own space: right-hand side e_0
+    Marg mg{};
+    if (!own) {
+      mg = marg_of(part, d.k);
+      if (part == 0) mg0 = mg; else mg1 = mg;
+      if (tid == 0) { links[pr.j].soff[part] = d.off; links[pr.j].sk[part] = d.k; links[pr.j].cst[part] = mg.c; }
+    }
     const bool stash = !PAIR && part == 1 && ps0 >= 0;     // second part of a two-part patient: solved in Q, parked in pS
     T* yv = stash ? Qv : P0;
-    solve(d, yv, false, [&](uint32_t x) { return own ? (x == 0 ? e0_scale<T>() : T(0)) : rg[x]; });
+    solve(d, yv, false, [&](uint32_t x) { return own ? (x == 0 ? e0_scale<T>() : T(0)) : marg_rhs(mg, x); });
     full_score += yv[(1u << d.k) - 1u];
     if (stash) for (uint32_t x = tid; x < (1u << d.k); x += SPB) pS[d.off + x] = yv[x];
     STAMP(1);
+  }
+  if (pr.kind == 3 && !PAIR && tid == 0) {                 // a part the row does not have: nothing feeds the joint adjoint
+    if (ps0 < 0) { links[pr.j].soff[0] = -1; links[pr.j].sk[0] = 0; links[pr.j].cst[0] = 0; }
+    if (ps1 < 0) { links[pr.j].soff[1] = -1; links[pr.j].sk[1] = 0; links[pr.j].cst[1] = 0; }
   }
   if (PAIR) {                                              // score of part 0 + score of part 1, in that order
     if (tid == 0) xch[pslot] = full_score;
@@ -263,13 +305,13 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     if (pr.kind == 3) {
       // the joint adjoint reads q of the marginal problem (k_psolve rhs_mode 3, k_tsolve); <q, rhs> on the upper half
       T* qg = qS + d.off;
-      const T* rg = rhsS + d.off;
+      const Marg& mg = part == 0 ? mg0 : mg1;
       const uint32_t half = V >> 1;
       T dot = 0;
       for (uint32_t x = tid; x < V; x += SPB) {
         const T qv = Qv[x];
         qg[x] = qv;
-        if (x >= half) dot += qv * rg[x];
+        if (x >= half) dot += qv * marg_rhs(mg, x);
       }
       dot = wave_sum_dpp(dot);
       if (lane == 0) red[w] = dot;
@@ -411,9 +453,10 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
 }
 
 #define SPATIENT_PARAMS const PatRec* __restrict__ pats, const Desc* __restrict__ dS, const Params<T>* __restrict__ par, \
-    const uint16_t* __restrict__ perm, const int* __restrict__ lvl, const T* __restrict__ rhsS, T* __restrict__ pS, \
+    const uint16_t* __restrict__ perm, const int* __restrict__ lvl, const Desc* __restrict__ dJ, const T* __restrict__ pi, \
+    JLink<T>* __restrict__ links, T* __restrict__ pS, \
     T* __restrict__ qS, T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots, double* __restrict__ lp
-#define SPATIENT_ARGS pats, dS, par, perm, lvl, rhsS, pS, qS, GS, bmS, dots, lp
+#define SPATIENT_ARGS pats, dS, par, perm, lvl, dJ, pi, links, pS, qS, GS, bmS, dots, lp
 
 // one size class per launch (the 1024-thread class)
 template <typename T, int SPB, int PPB, bool PAIR = false>
