@@ -1104,3 +1104,25 @@ def test_batched_kronvec_and_jacobi_step_fp32():
                 np.testing.assert_allclose(y[b], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
                 refz = lidg * (ref + rhs[b])
                 np.testing.assert_allclose(z[b], refz, rtol=0, atol=2e-5 * np.abs(refz).max())
+
+
+@pytest.mark.gpu
+def test_small_space_path_fp32_on_luad_cohort(golden):
+    """The small-space kernels (csrc/small.h: side-by-side marginal problems, in-kernel marginal right-hand sides) in
+    fp32 on the LUAD-reduced cohort, per patient against the fp64 engine at the fp32 bar: log-prob 1e-4 relative,
+    every gradient component within 2e-3 relative + 2e-5 absolute."""
+    from metmhn_amd import Engine
+    g = golden("luad_indep")
+    dat, lt, dp, dm = g["dat"], g["indep_theta"], g["indep_dp"], g["indep_dm"]
+    paired = np.flatnonzero(dat[:, -1] == 3)
+    rows = np.concatenate((paired, np.arange(0, dat.shape[0], 23)))          # every paired row + a stride of the others
+    sub = dat[rows]
+    res = {}
+    for dt in ("f64", "f32"):
+        with Engine((dat.shape[1] - 3) // 2, dtype=dt) as e:
+            e.set_cohort(sub)
+            res[dt] = e.patient_grads(lt, dp, dm)
+    np.testing.assert_allclose(res["f32"][0], res["f64"][0], rtol=1e-4, atol=1e-5)
+    for nm, x32, x64 in zip(("d_theta", "d_dp", "d_dm"), res["f32"][1:], res["f64"][1:]):
+        err, tol = _fp32_report(f"LUAD {nm}", x32, x64)
+        assert (err <= tol).all()
