@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Per-patient gradients of the small-space path (csrc/small.h) against the staged kernels it replaces (MMHN_SMALL=0) on
+300 paired rows at n = 16 with 10 - 16 active slots: which rows differ, their types and sizes (debugging aid).
+    python scripts/small_vs_staged.py"""
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from metmhn_amd import Engine, synthetic

@@ -1126,3 +1126,45 @@ def test_small_space_path_fp32_on_luad_cohort(golden):
     for nm, x32, x64 in zip(("d_theta", "d_dp", "d_dm"), res["f32"][1:], res["f64"][1:]):
         err, tol = _fp32_report(f"LUAD {nm}", x32, x64)
         assert (err <= tol).all()
+
+
+def _paired_rows(n, rng, kp, km, count):
+    """type-3 rows with kp PT-only and km MT-only events (disjoint), orders cycling 0 / 1 / 2"""
+    rows = []
+    for r in range(count):
+        ev = rng.permutation(n)
+        bits = np.zeros(2 * n, dtype=np.int8)
+        bits[2 * ev[:kp]] = 1
+        bits[2 * ev[kp:kp + km] + 1] = 1
+        rows.append(np.concatenate((bits, [1, r % 3, 3])).astype(np.int8))
+    return rows
+
+
+@pytest.mark.gpu
+def test_paired_rows_across_the_small_space_classes():
+    """Paired rows whose marginal problems fall in different size classes of csrc/small.h, in the three launch layouts
+    the engine chooses between: few rows with a 10-bit marginal (they ride in the merged 256-thread launch, two-part
+    rows side by side at 2 x 128 threads), more than 16 of them (own 1024-thread launch on a side stream), an 11-bit
+    marginal (never merged); orders 0 / 1 / 2 (both parts, PT-first only, MT-first only).  Per patient against the
+    optimised C oracle."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 11
+    lt, dp, dm = synthetic.random_params(n, seed=31)
+    rng = np.random.default_rng(5)
+    small = _paired_rows(n, rng, 2, 3, 12) + _paired_rows(n, rng, 5, 1, 9) + _paired_rows(n, rng, 3, 6, 9)
+    layouts = {
+        "merged (7 rows with a 10-bit part)": _paired_rows(n, rng, 2, 9, 10) + small,
+        "own launch (20 rows with a 10-bit part)": _paired_rows(n, rng, 2, 9, 15) + _paired_rows(n, rng, 9, 2, 15) + small,
+        "11 bits": _paired_rows(n, rng, 1, 10, 6) + _paired_rows(n, rng, 2, 9, 6) + small,
+    }
+    for name, rows in layouts.items():
+        dat = np.stack(rows)
+        lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+        with Engine(n) as e:
+            e.set_cohort(dat)
+            r = e.patient_grads(lt, dp, dm)
+        np.testing.assert_allclose(r[0], lp, rtol=1e-10, err_msg=name)
+        np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10, err_msg=name)
+        np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10, err_msg=name)
+        np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10, err_msg=name)
