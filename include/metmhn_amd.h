@@ -201,6 +201,10 @@ int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* sta
 int mmhn_bench_stream(mmhn_handle h, size_t bytes, int iters, int kind, double* gbps);
 int mmhn_get_counters(mmhn_handle h, mmhn_counters* out);
 int mmhn_reset_counters(mmhn_handle h);
+/* diagnostic of the window-layout solve (csrc/wsolve.h): out[6][64], out[i][lane] = the lane whose value `lane` receives
+ * through the exchange along lane bit i (DPP / swizzle / permute forms) - lane ^ (1 << i) on every lane that has the
+ * move (forward: bit i set, transposed: bit i clear).  No reference counterpart (the reference has no lanes). */
+int mmhn_debug_lane_moves(mmhn_handle h, int transposed, int* out);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,7 @@ SIGNATURES = {
     "mmhn_simulate": [C.c_void_p, f64p, f64p, f64p, C.c_int64, C.c_uint64, i8p, i8p],
     "mmhn_get_counters": [C.c_void_p, C.POINTER(Counters)],
     "mmhn_reset_counters": [C.c_void_p],
+    "mmhn_debug_lane_moves": [C.c_void_p, C.c_int, C.POINTER(C.c_int)],
 }
 OTHER_SYMBOLS = ("mmhn_destroy", "mmhn_last_error")
 

@@ -31,6 +31,7 @@
 #include "kernels.h"
 #include "small.h"
 #include "msolve.h"
+#include "wsolve.h"
 #include "sampler.h"
 
 namespace mmhn {
@@ -116,6 +117,10 @@ struct Batch {
   DevArr<MDesc> d_md;
   std::vector<int> olist;        // joint problems that stay on the tile kernels
   DevArr<int> d_olist;
+  // window path (wsolve.h): the same dispatch, 15 / 16 index bits on the chip
+  bool wpath = false;
+  std::vector<WDesc> wd;
+  DevArr<WDesc> d_wd;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
@@ -378,7 +383,9 @@ struct Engine : EngineBase {
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
                                 // second implementation, measured alternative - DESIGN.md 6); default: the tile kernels (k_psolve2)
-  DevArr<T> piM, qM;            // matrix path: solutions in matrix layout
+  int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
+  int wsolve_mode = 0;          // MMHN_WSOLVE=1: joint solves of per-patient batches in the window layout (wsolve.h)
+  DevArr<T> piM, qM;            // matrix / window path: solutions in their own layout
   DevArr<uint16_t> d_rowT, d_rankT;
   DevArr<MUnit> d_units;
   int n_cu = 256;
@@ -429,6 +436,9 @@ struct Engine : EngineBase {
       if (const char* sp = std::getenv("MMHN_PREP_SPLIT")) prep_split_max = std::atoi(sp);
       if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
       if (const char* ms = std::getenv("MMHN_MSOLVE")) msolve_mode = std::atoi(ms);
+      if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
+      if (wsolve_mode) msolve_mode = 0;
+      if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
       std::vector<uint16_t> rt(MROWS), rk(MROWS);
       matrix_rows(rt.data(), rk.data());
       d_rowT.alloc(MROWS); d_rankT.alloc(MROWS);
@@ -444,6 +454,8 @@ struct Engine : EngineBase {
     }
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -689,6 +701,24 @@ struct Engine : EngineBase {
     const int mk = std::max(b.maxkJ, 1);
     int nold = nJ;                                              // problems the tile kernels take
     const int* plist = nullptr;
+    if (b.wpath) {
+      // window path: the solution is written once (seeded half)
+      const int nW = (int)b.wd.size();
+      double bytes = 0;
+      for (const WDesc& w : b.wd) bytes += 0.5 * (double)(1ll << b.dJ[w.prob].k) * sizeof(T);
+      T* yw = tr ? qM.p : piM.p;
+      timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
+        const dim3 g((unsigned)std::min(nW, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
+        const size_t lds = wsolve_lds<T>();
+        if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
+        else hipLaunchKernelGGL((k_wsolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
+      });
+      hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
+      HIPCHECK(hipGetLastError());
+      nold = (int)b.olist.size();
+      plist = b.d_olist.p;
+      if (nold == 0) return;
+    }
     if (b.mpath) {
       // matrix path: the solution is written once (seeded half)
       const int nM = (int)b.md.size();
@@ -812,7 +842,7 @@ struct Engine : EngineBase {
         const int type = row[nc - 1];
         double el = 0;
         if (type == 3) {
-          el = (use_jacobi || msolve_mode ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
+          el = (use_jacobi || msolve_mode || wsolve_mode ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
                (kp + 1) * std::ldexp(1.0, kp) + (km + 1) * std::ldexp(1.0, km) + (ke + 2) * std::ldexp(1.0, ke);
         } else {
           el = 4.0 * std::ldexp(1.0, (type == 2 ? km : kp) + 1);
@@ -871,7 +901,7 @@ struct Engine : EngineBase {
       auto footprint = [&](long long vJ, long long vS, long long as, long long tabs, size_t nJp, size_t nSp, size_t npat) {
         const size_t small = (nSp * (size_t)(N * N + 64 + 1) + nJp * (size_t)(3 * N * N + 3 * N + 64)) * sizeof(T) +
                              nJp * sizeof(JLink<T>) + npat * ((size_t)stride() + 1) * sizeof(double) + npat * 2 * sizeof(T);
-        return (size_t)((use_jacobi || msolve_mode ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
+        return (size_t)((use_jacobi || msolve_mode || wsolve_mode ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
       };
       const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
                                     cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
@@ -936,6 +966,17 @@ struct Engine : EngineBase {
         }
         if (b.md.empty()) b.mpath = false;
         up(b.d_md, b.md);
+        up(b.d_olist, b.olist);
+      }
+      b.wd.clear();
+      b.wpath = wsolve_mode != 0 && !use_jacobi && (int)b.dJ.size() >= psolve_min && b.all_multi;
+      if (b.wpath) {
+        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
+          if (!window_ok<T>(b.dJ[pj])) { b.olist.push_back((int)pj); continue; }
+          b.wd.push_back(make_wdesc<T>(b.dJ[pj], (int)pj));
+        }
+        if (b.wd.empty()) b.wpath = false;
+        up(b.d_wd, b.wd);
         up(b.d_olist, b.olist);
       }
       b.mapX.clear();
@@ -1025,7 +1066,7 @@ struct Engine : EngineBase {
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS);
       mZ = std::max<size_t>(mZ, (size_t)zarena_elems((long long)b.dJ.size(), b.asize, N));
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
-      if (b.mpath) mvM = std::max(mvM, b.vecJ);
+      if (b.mpath || b.wpath) mvM = std::max(mvM, b.vecJ);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
     pi.alloc(mvJ); qJ.alloc(mvJ);
@@ -2184,6 +2225,20 @@ int mmhn_get_counters(mmhn_handle h, mmhn_counters* out) {
   else *out = static_cast<Engine<float>*>(h->impl)->cnt;
   API_END
 }
+int mmhn_debug_lane_moves(mmhn_handle h, int transposed, int* out) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(out, "null pointer");
+  DevArr<int> d;
+  d.alloc(6 * 64);
+  if (transposed) hipLaunchKernelGGL((k_lane_moves<true>), dim3(1), dim3(64), 0, h->impl->stream, d.p);
+  else hipLaunchKernelGGL((k_lane_moves<false>), dim3(1), dim3(64), 0, h->impl->stream, d.p);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(out, d.p, 6 * 64 * sizeof(int), hipMemcpyDeviceToHost, h->impl->stream));
+  HIPCHECK(hipStreamSynchronize(h->impl->stream));
+  API_END
+}
+
 int mmhn_reset_counters(mmhn_handle h) {
   API_BEGIN
   GUARD(h);

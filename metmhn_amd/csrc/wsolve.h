@@ -1,0 +1,613 @@
+// Joint triangular solves in the WINDOW layout (round 4): the class-sorted matrix formulation of msolve.h with
+// 15 (fp64) / 16 (fp32) of a patient's index bits on the chip instead of 12.
+//
+// On the seed = 1 half of a paired patient's space the operator is a Kronecker sum, D - Q = A_R (+) A_C over the two
+// tumour classes (reference: metmhn/jx/likelihood.py:231-262 solves it with k+1 Jacobi sweeps of
+// kronvec.py:499-539).  R ("rows") is the class with more bits, C ("columns") the other one; a seeded state is
+// (S, T) = (row subset, column subset) and
+//     y[S,T] = (rhs + sum_{i in S} rR_i(S \ i) y[S \ i, T] + sum_{b in T} rC_b(T \ b) y[S, T \ b]) / (dR[S] + dC[T])
+// (transposed: the sums run over the bits NOT in S / T, the neighbours are S | i / T | b, the rates are taken at
+// the state itself).  One 1024-thread workgroup solves one patient:
+//   * thread = row (w, l): the 6 lowest row bits are the LANE, the next 4 the WAVE of the thread;
+//   * a thread works on one BLOCK of NC = 2^RB columns per step and keeps the last H = 2^HB blocks - a WINDOW of
+//     H * NC columns - in registers: moves along the RB + HB lowest column bits are register arithmetic;
+//   * everything above (the other column bits, then the row bits beyond the tenth: the EXTERNAL index Sigma) is
+//     the thread's own earlier output, re-read from global memory: (K - 15) / 2 reads per state instead of 3.5;
+//   * moves along the lane bits read the NEIGHBOUR LANE'S WINDOW REGISTERS directly (DPP / swizzle / bpermute, no
+//     LDS storage): a lane of lane-level m (popcount of l) runs m whole windows behind, so the block it needs is
+//     exactly what slot beta of the lower lane's window still holds from that lane's previous window pass;
+//   * moves along the wave bits go through a two-slot ring in LDS: a wave of wave-level lam runs lam blocks behind,
+//     its lower neighbour waves published the block one step earlier; one LDS-only barrier per step.
+// Every wave therefore works on ONE static window slot per step (the step loop is unrolled H times), no lane
+// ever waits for another lane of its wave, and no level ever idles except while the pipeline fills and drains.
+// oracle/wschedule.py is a scalar model of exactly this schedule (tests/test_oracle_golden.py runs it).
+//
+// Storage of the seeded half ("window layout"):
+//     position(S, T) = (((Sigma * H + beta) * 1024 + rho(w, l)) * NC + c,   T = c | beta << RB | Tx << (RB + HB),
+//     Sigma = Tx | Sx << nXc,  S = l | w << 6 | Sx << 10,
+// rho sorts the rows of a block by lane-level so that the lanes of a wave which work on the same external index
+// (= the same lane-level) touch one contiguous run of memory.  The seed = 0 half keeps its natural positions.
+#pragma once
+#include "msolve.h"
+
+namespace mmhn {
+
+constexpr int WLB = 6, WWB = 4, WTB = WLB + WWB;   // lane bits, wave bits, thread bits
+constexpr int WROWS = 1 << WTB;                    // rows of a block = threads of a workgroup
+constexpr int WKR = 15;                            // most row-class bits (five beyond the thread bits)
+constexpr int WNXR = WKR - WTB;
+
+template <typename T> struct WCfg;
+// RB: column bits of a block, HB: blocks of a window, KC: most column-class bits (their rate table lives in LDS),
+// PAD: elements between the table rows of two external column settings (16 bytes: the lanes of a wave differ in it)
+template <> struct WCfg<double> { static constexpr int RB = 2, HB = 3, KC = 9, PAD = 2; };
+template <> struct WCfg<float> { static constexpr int RB = 3, HB = 3, KC = 10, PAD = 4; };
+
+// static description of one joint problem on the window path (host-built, set_cohort)
+struct WDesc {
+  int prob;                  // index into the batch's joint descriptors
+  int kR, kC, majP;          // row-class bits, column-class bits, 1: the row class is P
+  int nXc, nXr;              // external column bits (kC - RB - HB), external row bits (kR - 10)
+  uint32_t rowmask, colmask; // natural index bits of the two classes
+  uint32_t pairRowC;         // compact row bits whose event is also active in the other tumour
+  uint32_t loneRowC;         // compact row bits whose partner slot is inactive
+  int8_t rb[16];             // natural bit of row bit i
+  int8_t cb[16];             // natural bit of column bit i
+  int8_t prt[16];            // column bit of the partner of row bit i, -1: none
+};
+
+template <typename T>
+inline bool window_ok(const Desc& d) {
+  if (d.mode != JOINT || d.seedbit != d.k - 1) return false;
+  const int kP = popc(d.maskP), kM = popc(d.maskM);
+  const int kR = kP >= kM ? kP : kM, kC = kP >= kM ? kM : kP;
+  return kR >= WTB && kR <= WKR && kC >= WCfg<T>::RB + WCfg<T>::HB && kC <= WCfg<T>::KC && popc(d.pairP) <= MKE;
+}
+template <typename T>
+inline WDesc make_wdesc(const Desc& d, int prob) {
+  WDesc w{};
+  w.prob = prob;
+  const int kP = popc(d.maskP), kM = popc(d.maskM);
+  w.majP = kP >= kM ? 1 : 0;
+  w.rowmask = w.majP ? d.maskP : d.maskM;
+  w.colmask = w.majP ? d.maskM : d.maskP;
+  int nr = 0, nc = 0;
+  for (int b = 0; b < d.k; ++b) {
+    if ((w.rowmask >> b) & 1u) w.rb[nr++] = (int8_t)b;
+    else if ((w.colmask >> b) & 1u) w.cb[nc++] = (int8_t)b;
+  }
+  w.kR = nr; w.kC = nc;
+  w.nXc = nc - WCfg<T>::RB - WCfg<T>::HB;
+  w.nXr = nr - WTB;
+  for (int i = 0; i < nr; ++i) {
+    const int b = w.rb[i];
+    w.prt[i] = -1;
+    if ((d.lone >> b) & 1u) { w.loneRowC |= 1u << i; continue; }
+    const int pb = w.majP ? b + 1 : b - 1;                     // partner slot: the M bit sits right above its P bit
+    w.pairRowC |= 1u << i;
+    for (int j = 0; j < nc; ++j) if (w.cb[j] == pb) w.prt[i] = (int8_t)j;
+  }
+  return w;
+}
+
+// rows of a block sorted by lane-level: rho(w, l) = 16 * (rows of lower levels) + w * C(6, m) + rank of l in its level
+struct W6 {
+  uint8_t rank[64], order[64], off[8], cnt[8];
+};
+constexpr W6 make_w6() {
+  W6 t{};
+  int pos = 0;
+  for (int m = 0; m <= 6; ++m) {
+    t.off[m] = (uint8_t)pos;
+    int r = 0;
+    for (int l = 0; l < 64; ++l) {
+      int pc = 0;
+      for (int b = 0; b < 6; ++b) pc += (l >> b) & 1;
+      if (pc == m) { t.rank[l] = (uint8_t)r++; t.order[pos++] = (uint8_t)l; }
+    }
+    t.cnt[m] = (uint8_t)r;
+  }
+  t.off[7] = 64; t.cnt[7] = 0;
+  return t;
+}
+__host__ __device__ inline uint32_t wrho(uint32_t w, uint32_t l) {
+  constexpr W6 t = make_w6();
+  const int m = popc32(l);
+  return 16u * t.off[m] + w * t.cnt[m] + t.rank[l];
+}
+// inverse: row index w << 6 | l of storage row r
+__host__ __device__ inline uint32_t wrho_inv(uint32_t r) {
+  constexpr W6 t = make_w6();
+  int m = 0;
+  while (r >= 16u * t.off[m + 1]) ++m;
+  const uint32_t q = r - 16u * t.off[m];
+  return ((q / t.cnt[m]) << 6) | t.order[t.off[m] + q % t.cnt[m]];
+}
+template <typename T>
+__host__ __device__ inline long long wpos(uint32_t Sigma, uint32_t beta, uint32_t rho, uint32_t c) {
+  return ((((long long)((Sigma << WCfg<T>::HB) | beta) << WTB) + rho) << WCfg<T>::RB) + c;
+}
+// position of the seeded natural state x (seeding bit stripped) inside the seeded half
+template <typename T>
+__device__ inline long long wpos_nat(const WDesc& w, uint32_t x) {
+  constexpr int RB = WCfg<T>::RB, HB = WCfg<T>::HB;
+  const uint32_t S = pext32(x, w.rowmask), Tc = pext32(x, w.colmask);
+  const uint32_t Sigma = (Tc >> (RB + HB)) | ((S >> WTB) << w.nXc);
+  return wpos<T>(Sigma, (Tc >> RB) & ((1u << HB) - 1u), wrho((S >> WLB) & ((1u << WWB) - 1u), S & 63u), Tc & ((1u << RB) - 1u));
+}
+
+// value of the lane that differs in lane bit I, for the lanes that have the move (forward: bit set, the lane below;
+// transposed: bit clear, the lane above); the other lanes get some finite value of the wave
+template <int I, bool TR>
+__device__ __forceinline__ int lane_nbr32(int v, int lane) {
+  if constexpr (I == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  else if constexpr (I == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  else if constexpr (I == 2) return __builtin_amdgcn_update_dpp(0, v, TR ? 0x104 : 0x114, 0xF, 0xF, true);   // row_shl:4 / row_shr:4
+  else if constexpr (I == 3) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+  else if constexpr (I == 4) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                     // swap the halves of 32 lanes
+  else return __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v);
+}
+template <int I, bool TR>
+__device__ __forceinline__ double lane_nbr(double v, int lane) {
+  return __hiloint2double(lane_nbr32<I, TR>(__double2hiint(v), lane), lane_nbr32<I, TR>(__double2loint(v), lane));
+}
+template <int I, bool TR>
+__device__ __forceinline__ float lane_nbr(float v, int lane) {
+  return __int_as_float(lane_nbr32<I, TR>(__float_as_int(v), lane));
+}
+// diagnostic (mmhn_debug_lane_moves): out[I * 64 + lane] = lane id received through lane_nbr<I>
+template <bool TR>
+__global__ void k_lane_moves(int* out) {
+  const int lane = threadIdx.x & 63;
+  out[0 * 64 + lane] = lane_nbr32<0, TR>(lane, lane);
+  out[1 * 64 + lane] = lane_nbr32<1, TR>(lane, lane);
+  out[2 * 64 + lane] = lane_nbr32<2, TR>(lane, lane);
+  out[3 * 64 + lane] = lane_nbr32<3, TR>(lane, lane);
+  out[4 * 64 + lane] = lane_nbr32<4, TR>(lane, lane);
+  out[5 * 64 + lane] = lane_nbr32<5, TR>(lane, lane);
+}
+
+template <typename T>
+struct WLds {
+  using C = WCfg<T>;
+  static constexpr int NC = 1 << C::RB, WIN = 1 << (C::RB + C::HB);
+  static constexpr int RCS = (1 << C::KC) + (C::PAD << (C::KC - C::RB - C::HB));   // padded length of one table over the column sets
+  static constexpr int ring = 0;                                        // [2][NC * sizeof(T) / 16][WROWS] 16-byte pieces
+  static constexpr int Rc = ring + 2 * NC * WROWS;                      // [KC][RCS] rate of column bit b from column set T
+  static constexpr int dC = Rc + C::KC * RCS;                           // [RCS] column part of the diagonal
+  static constexpr int Lr = dC + RCS;                                   // [WKR][64] row-bit rate: product over the lane bits
+  static constexpr int Ur = Lr + WKR * 64;                              // [WKR][16] ... base rate and the wave bits
+  static constexpr int Er = Ur + WKR * 16;                              // [WKR][32] ... the external row bits
+  static constexpr int e0 = Er + WKR * 32;                              // [2^ke] eq-block solution
+  static constexpr int se = e0 + (1 << MKE);                            // [2^ke] forward: seeding inflow of eq state e
+  static constexpr int end = se + (1 << MKE);
+  static constexpr size_t bytes = (size_t)end * sizeof(T) + 64 * sizeof(int);
+};
+template <typename T>
+constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
+
+// ------------------------------------------------------------------------------------
+// k_wsolve: y = (D - Q)^-1 rhs (TR: transposed) of the joint problems in `wds`, window layout.
+//   forward: rhs = E0 e_0 (the seed = 0 lattice over the paired events is solved first, seeding carries it into
+//            the seeded half);  transposed: rhs = D_obs * scatter(q_S) from `links` (likelihood.py:573-575,
+//            617-618), the seed = 0 lattice follows the seeded half.
+// Persistent: workgroup b takes problems b, b + gridDim.x, ...
+// ------------------------------------------------------------------------------------
+template <typename T, bool TR>
+__global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs, const WDesc* __restrict__ wds, int nw,
+                                                  T* y, const T* __restrict__ tab,
+                                                  const JLink<T>* __restrict__ links, const T* __restrict__ qS) {
+  using C = WCfg<T>;
+  using L = WLds<T>;
+  constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, WB = RB + HB, WIN = 1 << WB, PAD = C::PAD, RCS = L::RCS;
+  constexpr int QE = 16 / (int)sizeof(T);                      // elements of a 16-byte piece
+  constexpr int NQ = NC / QE;                                  // pieces of a block row (2)
+  typedef T VecT __attribute__((ext_vector_type(NC)));
+  typedef T QT __attribute__((ext_vector_type(QE)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  struct Raw { u32x4 q[NQ]; };
+  static_assert(sizeof(Raw) == sizeof(VecT) && NQ == 2, "a row of a block is two 16-byte accesses");
+  constexpr uint32_t BLKB = WROWS * sizeof(VecT);              // bytes of one block
+  constexpr int BSH = HB + WTB + 5;                            // log2 of the bytes of one external index (H blocks)
+  static_assert(sizeof(VecT) == 32, "block rows are 32 bytes");
+  constexpr uint32_t OOB = 0x80000000u;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* const lds = reinterpret_cast<T*>(smem);
+  T* const ring = lds + L::ring;
+  T* const Rc = lds + L::Rc;
+  T* const dCt = lds + L::dC;
+  T* const Lr = lds + L::Lr;
+  T* const Ur = lds + L::Ur;
+  T* const Er = lds + L::Er;
+  T* const e0 = lds + L::e0;
+  T* const se = lds + L::se;
+  int* const bits = reinterpret_cast<int*>(lds + L::end);      // [0..15] rb, [16..31] cb, [32..47] prt
+  T* const thc = ring;                                         // [k][k] effects between index bits: only while the tables are built
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = TR ? WLB - __popc(lane) : __popc(lane);        // lane-level: windows this lane runs behind
+  const int lam = TR ? WWB - __popc(wv) : __popc(wv);          // wave-level: blocks this wave runs behind
+  const uint32_t voff = wrho((uint32_t)wv, (uint32_t)lane) * (uint32_t)sizeof(VecT);
+  auto rcidx = [](uint32_t Tc) -> uint32_t { return Tc + (Tc >> WB) * PAD; };
+
+  for (int it = blockIdx.x; it < nw; it += gridDim.x) {
+    const WDesc& wd = wds[it];
+    const int prob = sgpr(wd.prob);
+    const Desc& d = descs[prob];
+    const int k = sgpr(d.k), kR = sgpr(wd.kR), kC = sgpr(wd.kC), nXc = sgpr(wd.nXc), nXr = sgpr(wd.nXr);
+    const int nX = nXc + nXr;
+    const bool majP = sgpr(wd.majP) != 0;
+    const long long base = sgpr64(d.off), toff = sgpr64(d.toff);
+    const int seedb = k - 1;
+    const T* dP = tab + toff + rate_table_size(k);
+    const T* dM = dP + (1ll << __popc(sgpr(d.maskP)));
+    const T* dRg = majP ? dP : dM;
+    const T* dCg = majP ? dM : dP;
+    const long long half = 1ll << (k - 1);
+    T* const ym = y + base + half;                             // seeded half, window layout
+    __syncthreads();                                           // previous problem done with the tables and the ring
+    {
+      const T* src = tab + toff;
+      for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
+      if (tid < 16) bits[tid] = wd.rb[tid];
+      else if (tid < 32) bits[tid] = wd.cb[tid - 16];
+      else if (tid < 48) bits[tid] = wd.prt[tid - 32];
+    }
+    __syncthreads();
+    // ---- tables: rates of the column-class events from every column set; the row-class rates as three factors
+    for (uint32_t e = tid; e < ((uint32_t)kC << kC); e += WROWS) {
+      const int b = (int)(e >> kC), nb = bits[16 + b];
+      const uint32_t Tc = e & ((1u << kC) - 1u);
+      T r = thc[nb * k + nb];
+      for (int i = 0; i < kC; ++i) if (i != b && ((Tc >> i) & 1u)) r *= thc[nb * k + bits[16 + i]];
+      Rc[b * RCS + rcidx(Tc)] = r;
+    }
+    for (uint32_t e = tid; e < (1u << kC); e += WROWS) dCt[rcidx(e)] = dCg[e];
+    for (int e = tid; e < kR * 64; e += WROWS) {
+      const int i = e >> 6, l = e & 63, nb = bits[i];
+      T r = T(1);
+      for (int j = 0; j < WLB; ++j) if (j != i && ((l >> j) & 1)) r *= thc[nb * k + bits[j]];
+      Lr[e] = r;
+    }
+    for (int e = tid; e < kR * 16; e += WROWS) {
+      const int i = e >> 4, u = e & 15, nb = bits[i];
+      T r = thc[nb * k + nb];
+      for (int j = 0; j < WWB; ++j) if (WLB + j != i && ((u >> j) & 1)) r *= thc[nb * k + bits[WLB + j]];
+      Ur[e] = r;
+    }
+    for (int e = tid; e < kR * 32; e += WROWS) {
+      const int i = e >> 5, u = e & 31, nb = bits[i];
+      T r = T(1);
+      for (int j = 0; j < nXr; ++j) if (WTB + j != i && ((u >> j) & 1)) r *= thc[nb * k + bits[WTB + j]];
+      Er[e] = r;
+    }
+    // ---- seed = 0 part: lattice over the paired events (only PT == MT states carry values)
+    auto solve_eq = [&]() {
+      const uint32_t pairP = sgpr(d.pairP);
+      const int ke = __popc(pairP);
+      const T* dE = dM + (1ll << __popc(sgpr(d.maskM)));
+      const uint32_t VE = 1u << ke;
+      const T seed_base = thc[seedb * k + seedb];
+      for (int s = 0; s <= ke; ++s) {
+        const int level = TR ? ke - s : s;
+        for (uint32_t e = tid; e < VE; e += WROWS) {
+          if (__popc(e) != level) continue;
+          const uint32_t xp = pdep32(e, pairP);
+          const uint32_t x0 = xp | (xp << 1);
+          T z = (!TR && e == 0) ? e0_scale<T>() : T(0);
+          T rs = seed_base;
+          for (uint32_t m2 = xp; m2; m2 &= m2 - 1) rs *= thc[seedb * k + (__ffs(m2) - 1)];
+          if (!TR) {
+            for (uint32_t mm = xp; mm; mm &= mm - 1) {
+              const int bP = __ffs(mm) - 1;
+              T r = thc[bP * k + bP];
+              for (uint32_t m2 = xp & ~(1u << bP); m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
+              z += r * e0[pext32(xp & ~(1u << bP), pairP)];
+            }
+          } else {
+            for (uint32_t mm = pairP & ~xp; mm; mm &= mm - 1) {
+              const int bP = __ffs(mm) - 1;
+              T r = thc[bP * k + bP];
+              for (uint32_t m2 = xp; m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
+              z += r * e0[pext32(xp | (1u << bP), pairP)];
+            }
+            z += rs * ym[wpos_nat<T>(wd, x0)];
+          }
+          const T v = z / dE[e];
+          e0[e] = v;
+          if (!TR) se[e] = rs * v;
+          y[base + x0] = v;
+        }
+        __syncthreads();
+      }
+    };
+    if (!TR) solve_eq();
+    __syncthreads();                                           // tables complete; thc (ring area) is free from here on
+    // ---- per-lane constants of the patient
+    const JLink<T>* Lk = links + prob;
+    const int rowpart = majP ? 0 : 1, colpart = 1 - rowpart;
+    const uint32_t NXS = 1u << nX, mXc = (1u << nXc) - 1u;
+    const int NSIG = (int)NXS + WLB;
+    const uint32_t Sxfull = (1u << nXr) - 1u, Txfull = mXc;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sgpr64((long long)reinterpret_cast<char*>(ym))), 0,
+                                                        (int)sgpr((uint32_t)((unsigned long long)half * sizeof(T))), 0x00020000);
+    auto ld_row = [&](uint32_t off, uint32_t soff) -> VecT {
+      Raw r;
+      r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)soff, 0);
+      r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, (int)soff, 0);
+      return __builtin_bit_cast(VecT, r);
+    };
+    auto st_row = [&](uint32_t off, uint32_t soff, const VecT& v) {
+      const Raw r = __builtin_bit_cast(Raw, v);
+      __builtin_amdgcn_raw_buffer_store_b128(r.q[0], rsrc, (int)off, (int)soff, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(r.q[1], rsrc, (int)off + 16, (int)soff, 0);
+    };
+    auto lds_vec = [&](const T* p) -> VecT {                   // NC consecutive elements, 16-byte aligned
+      Raw r;
+      r.q[0] = *reinterpret_cast<const u32x4*>(p);
+      r.q[1] = *reinterpret_cast<const u32x4*>(p + QE);
+      return __builtin_bit_cast(VecT, r);
+    };
+    VecT Wd[H];                                                // the window
+#pragma unroll
+    for (int b = 0; b < H; ++b)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) Wd[b][c] = T(0);
+    // ---- state of the current window pass (per lane: the lanes of a wave differ in their external index)
+    // Sigma: external index (0 on a lane that is outside the pipeline), soff: byte offset of its blocks (beyond the
+    // buffer on such a lane: its stores are dropped, its loads return zeros), rcb: offset of its column tables
+    uint32_t Sigma = 0, rcb = 0, goff = 0, soff = OOB;
+    T cL[WLB], dRv = T(1);
+    uint32_t hitT = 0xffffffffu, hitE = 0;
+    // (thread-derived values are re-derived from an opaque copy of the thread id inside every step / pass: hipcc would
+    // otherwise hoist a dozen loop-invariant LDS addresses out of the step loop and spill them)
+    auto opaque_tid = [&]() -> uint32_t { uint32_t t = (uint32_t)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+    auto begin_pass = [&](int sig) {
+      const uint32_t tt = opaque_tid(), ln = tt & 63u;
+      const int Sg = sig - (TR ? WLB - __popc(ln) : __popc(ln));
+      const bool act = (unsigned)Sg < NXS;
+      Sigma = act ? (TR ? NXS - 1u - (uint32_t)Sg : (uint32_t)Sg) : 0u;
+      const uint32_t Sx = Sigma >> nXc;
+      rcb = (Sigma & mXc) * (uint32_t)(WIN + PAD);
+      goff = (Sigma << BSH) + voff;
+      soff = act ? goff : OOB;
+#pragma unroll
+      for (int i = 0; i < WLB; ++i) {
+        const bool has = TR ? !((ln >> i) & 1u) : ((ln >> i) & 1u);
+        const T r = Lr[i * 64 + ln] * Ur[i * 16 + wv] * Er[i * 32 + Sx];
+        cL[i] = has ? r : T(0);
+      }
+      dRv = dRg[tt | (Sx << WTB)];
+      if (!TR) {
+        // forward right-hand side: seeding enters row S at the one column whose paired events are those of S
+        const uint32_t S = tt | (Sx << WTB);
+        uint32_t hT = 0, e = 0, ebit = 1u;
+        for (uint32_t pm = sgpr(wd.pairRowC); pm; pm &= pm - 1) {          // (scalar loop: at most MKE pairs)
+          const int i = __ffs(pm) - 1;
+          if ((S >> i) & 1u) { hT |= 1u << bits[32 + i]; e |= ebit; }
+          ebit <<= 1;
+        }
+        hitT = (S & sgpr(wd.loneRowC)) ? 0xffffffffu : hT;
+        hitE = e;
+      }
+    };
+    // ---- one step: the block (Sigma, beta) of every row of the wave
+    auto step = [&](auto BIc, int gpar) {
+      constexpr int BI = decltype(BIc)::value;
+      constexpr int beta = TR ? H - 1 - BI : BI;
+      constexpr uint32_t boff = (uint32_t)beta * BLKB;
+      const uint32_t tt = opaque_tid(), ln = tt & 63u;
+      T acc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = T(0);
+      // external moves: the thread's own earlier blocks.  A move that does not exist is requested beyond the end of
+      // the buffer (zeros come back, nothing is touched): no per-move control flow.
+      auto ext_off = [&](int j) -> uint32_t {
+        const bool has = TR ? !((Sigma >> j) & 1u) : ((Sigma >> j) & 1u);
+        return (has && soff != OOB) ? (goff ^ (1u << (j + BSH))) : OOB;
+      };
+      auto ext_take = [&](int j, const VecT& nv) {
+        if (j < nXc) {
+          // column move: rate of column bit WB + j from the source column set
+          const uint32_t Tx = Sigma & mXc;
+          const uint32_t srcTx = TR ? Tx : (Tx & ~(1u << j));
+          const VecT rr = lds_vec(Rc + (WB + j) * RCS + srcTx * (uint32_t)(WIN + PAD) + beta * NC);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], nv[c], acc[c]);
+        } else {
+          const T r = Lr[(WTB + (j - nXc)) * 64 + ln] * Ur[(WTB + (j - nXc)) * 16 + wv] * Er[(WTB + (j - nXc)) * 32 + (Sigma >> nXc)];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = fma_m(r, nv[c], acc[c]);
+        }
+      };
+      VecT ev0, ev1;
+      if (nX > 0) ev0 = ld_row(ext_off(0), boff);
+      if (nX > 1) ev1 = ld_row(ext_off(1), boff);
+      __builtin_amdgcn_sched_barrier(0);
+      // lane moves: the neighbour lane's window slot (its previous window pass = this lane's external index)
+      {
+        const VecT old = Wd[beta];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          acc[c] = fma_m(cL[0], lane_nbr<0, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[1], lane_nbr<1, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[2], lane_nbr<2, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[3], lane_nbr<3, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[4], lane_nbr<4, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[5], lane_nbr<5, TR>(old[c], (int)ln), acc[c]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (nX > 0) ext_take(0, ev0);
+      if (nX > 1) ext_take(1, ev1);
+      if (nX > 2) {
+        ev0 = ld_row(ext_off(2), boff);
+        if (nX > 3) ev1 = ld_row(ext_off(3), boff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // wave moves: the block the neighbour wave published one step ago
+      {
+        const T* rs = ring + (uint32_t)(gpar ^ 1) * (NC * WROWS);
+#pragma unroll
+        for (int j = 0; j < WWB; ++j) {
+          const bool has = TR ? !((wv >> j) & 1) : ((wv >> j) & 1);
+          if (has) {                                           // wave-uniform
+            const uint32_t row = tt ^ (64u << j);
+            Raw r;
+            r.q[0] = *reinterpret_cast<const u32x4*>(rs + row * QE);
+            r.q[1] = *reinterpret_cast<const u32x4*>(rs + WROWS * QE + row * QE);
+            const VecT nv = __builtin_bit_cast(VecT, r);
+            const T cw = Lr[(WLB + j) * 64 + ln] * Ur[(WLB + j) * 16 + wv] * Er[(WLB + j) * 32 + (Sigma >> nXc)];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fma_m(cw, nv[c], acc[c]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // window moves: own blocks of this window pass
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const bool has = TR ? !((beta >> j) & 1) : ((beta >> j) & 1);
+        if (has) {                                             // compile-time
+          const int sb = beta ^ (1 << j);
+          const VecT rr = lds_vec(Rc + (RB + j) * RCS + rcb + (TR ? beta : sb) * NC);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], Wd[sb][c], acc[c]);
+        }
+      }
+      if (nX > 2) {
+        ext_take(2, ev0);
+        if (nX > 3) ext_take(3, ev1);
+        for (int j0 = 4; j0 < nX; j0 += 2) {                   // (spaces of more than 20 bits)
+          ev0 = ld_row(ext_off(j0), boff);
+          if (j0 + 1 < nX) ev1 = ld_row(ext_off(j0 + 1), boff);
+          ext_take(j0, ev0);
+          if (j0 + 1 < nX) ext_take(j0 + 1, ev1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // right-hand side
+      const uint32_t Tblk = ((Sigma & mXc) << HB) | (uint32_t)beta;       // column set of the block >> RB
+      if (!TR) {
+        if (__builtin_amdgcn_ballot_w64((hitT >> RB) == Tblk) != 0ull) {  // (rare: skipped by a scalar branch)
+          const T hv = (hitT >> RB) == Tblk ? se[hitE] : T(0);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c] += ((hitT & (uint32_t)(NC - 1)) == (uint32_t)c) ? hv : T(0);
+        }
+      } else {
+        if (wv == WROWS / 64 - 1) {                                       // the last row of the last external row setting
+          if (ln == 63u && (Sigma >> nXc) == Sxfull && soff != OOB && Lk->soff[rowpart] >= 0) {
+            const T* qr = qS + Lk->soff[rowpart] + (1ll << (Lk->sk[rowpart] - 1)) + ((long long)Tblk << RB);
+            const T cr = Lk->cst[rowpart];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += cr * qr[c];
+          }
+        }
+        if (beta == H - 1) {                                              // the last column
+          if ((Sigma & mXc) == Txfull && soff != OOB && Lk->soff[colpart] >= 0)
+            acc[NC - 1] += Lk->cst[colpart] * qS[Lk->soff[colpart] + (1ll << (Lk->sk[colpart] - 1)) + (tt | ((Sigma >> nXc) << WTB))];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the block itself: moves along the RB lowest column bits (only the rates in use are fetched), diagonal
+      const T* rcp_ = Rc + rcb + beta * NC;
+      const VecT dcv = lds_vec(dCt + rcb + beta * NC);
+      VecT Y;
+      if (!TR) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          T z = acc[c];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            if ((c >> r) & 1) z = fma_m(rcp_[r * RCS + (c ^ (1 << r))], Y[c ^ (1 << r)], z);
+          Y[c] = z * fast_rcp(dRv + dcv[c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = NC - 1; c >= 0; --c) {
+          T z = acc[c];
+#pragma unroll
+          for (int r = 0; r < RB; ++r)
+            if (!((c >> r) & 1)) z = fma_m(rcp_[r * RCS + c], Y[c | (1 << r)], z);
+          Y[c] = z * fast_rcp(dRv + dcv[c]);
+        }
+      }
+      Wd[beta] = Y;
+      if (TR ? wv != 0 : wv != WROWS / 64 - 1) {               // some wave above / below reads it
+        T* ws = ring + (uint32_t)gpar * (NC * WROWS);
+        const Raw r = __builtin_bit_cast(Raw, Y);
+        *reinterpret_cast<u32x4*>(ws + tt * QE) = r.q[0];
+        *reinterpret_cast<u32x4*>(ws + WROWS * QE + tt * QE) = r.q[1];
+      }
+      st_row(soff, boff, Y);
+    };
+    // ---- the pipeline: wave-level lam delays the wave by lam steps, lane-level m delays a lane by m window passes
+    for (int s = 0; s < lam; ++s) lds_barrier();
+    for (int sig = 0; sig < NSIG; ++sig) {
+      begin_pass(sig);
+      const int g0 = lam & 1;                                  // parity of the global step (H is even)
+      step(IC<0>{}, g0); lds_barrier();
+      step(IC<1>{}, g0 ^ 1); lds_barrier();
+      if constexpr (H > 2) {
+        step(IC<2 % H>{}, g0); lds_barrier();
+        step(IC<3 % H>{}, g0 ^ 1); lds_barrier();
+      }
+      if constexpr (H > 4) {
+        step(IC<4 % H>{}, g0); lds_barrier();
+        step(IC<5 % H>{}, g0 ^ 1); lds_barrier();
+        step(IC<6 % H>{}, g0); lds_barrier();
+        step(IC<7 % H>{}, g0 ^ 1); lds_barrier();
+      }
+      static_assert(H == 2 || H == 4 || H == 8, "window of 2, 4 or 8 blocks");
+    }
+    for (int s = lam; s < WWB; ++s) lds_barrier();
+    if (TR) {
+      __syncthreads();                                         // every store of the seeded half has landed; the ring is free
+      const T* src = tab + toff;
+      for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
+      __syncthreads();
+      solve_eq();
+    }
+  }
+}
+
+// window layout -> natural index order (seeded half; the PT == MT states of the seed = 0 half are copied)
+template <typename T>
+__global__ __launch_bounds__(WROWS) void k_wconvert(const Desc* __restrict__ descs, const WDesc* __restrict__ wds,
+                                                    const T* __restrict__ yw, T* __restrict__ yn) {
+  constexpr int RB = WCfg<T>::RB, HB = WCfg<T>::HB, NC = 1 << RB;
+  const WDesc& wd = wds[blockIdx.x];
+  const Desc& d = descs[wd.prob];
+  const int k = d.k, tid = threadIdx.x;
+  const long long half = 1ll << (k - 1);
+  const uint32_t rho = wrho((uint32_t)tid >> 6, (uint32_t)tid & 63u);
+  const uint32_t nblk = 1u << (wd.nXc + wd.nXr + HB);
+  const T* src = yw + d.off + half;
+  T* dst = yn + d.off + half;
+  uint32_t rowlo = 0;
+  for (int i = 0; i < WTB; ++i) if ((tid >> i) & 1) rowlo |= 1u << wd.rb[i];
+  for (uint32_t B = blockIdx.y; B < nblk; B += gridDim.y) {
+    const uint32_t Sigma = B >> HB, beta = B & ((1u << HB) - 1u);
+    const uint32_t Tx = Sigma & ((1u << wd.nXc) - 1u), Sx = Sigma >> wd.nXc;
+    uint32_t xr = rowlo;
+    for (int i = 0; i < wd.nXr; ++i) if ((Sx >> i) & 1u) xr |= 1u << wd.rb[WTB + i];
+    const uint32_t Tc0 = (beta << RB) | (Tx << (RB + HB));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const uint32_t Tc = Tc0 | (uint32_t)c;
+      uint32_t xc = 0;
+      for (int i = 0; i < wd.kC; ++i) if ((Tc >> i) & 1u) xc |= 1u << wd.cb[i];
+      dst[xr | xc] = src[wpos<T>(Sigma, beta, rho, (uint32_t)c)];
+    }
+  }
+  if (blockIdx.y == 0) {
+    const uint32_t VE = 1u << __popc(d.pairP);
+    for (uint32_t e = tid; e < VE; e += WROWS) {
+      const uint32_t xp = pdep32(e, d.pairP);
+      const uint32_t x0 = xp | (xp << 1);
+      yn[d.off + x0] = yw[d.off + x0];
+    }
+  }
+}
+
+}  // namespace mmhn

@@ -336,3 +336,9 @@ class Engine:
 
     def reset_counters(self):
         _lib.check(self.lib.mmhn_reset_counters(self.h))
+
+    def debug_lane_moves(self, transposed=False):
+        """out[i][lane] = source lane of the window solve's exchange along lane bit i (csrc/wsolve.h)."""
+        out = (C.c_int * (6 * 64))()
+        _lib.check(self.lib.mmhn_debug_lane_moves(self.h, int(bool(transposed)), out))
+        return np.array(out[:], dtype=np.int64).reshape(6, 64)

@@ -1168,3 +1168,66 @@ def test_paired_rows_across_the_small_space_classes():
         np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10, err_msg=name)
         np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10, err_msg=name)
         np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_window_solve_lane_moves():
+    """The six lane exchanges of the window solve (csrc/wsolve.h: DPP quad permutes, row shifts / rotate, swizzle,
+    bpermute): a lane that has the move along bit i receives from lane ^ (1 << i)."""
+    from metmhn_amd import Engine
+    with Engine(4) as e:
+        for tr in (False, True):
+            src = e.debug_lane_moves(transposed=tr)
+            for i in range(6):
+                for lane in range(64):
+                    has = ((lane >> i) & 1) == (0 if tr else 1)
+                    if has:
+                        assert src[i, lane] == lane ^ (1 << i), (tr, i, lane, src[i, lane])
+
+
+@pytest.mark.gpu
+def test_window_layout_solves_match_cpu_port(monkeypatch):
+    """MMHN_WSOLVE=1: the joint solves in the window layout (csrc/wsolve.h - 15 index bits on the chip: lane bits
+    exchanged out of the neighbour lane's register window, wave bits through an LDS ring, the rest the thread's own
+    history) against oracle/metmhn_fast.c on n = k = 20 patients of every order, and against the tile kernels on a
+    cohort that mixes shapes the window path takes (10 - 15 row-class bits, 5 - 9 column-class bits, either class as
+    rows, no / many pairs) with shapes it leaves to the tile kernels (per-problem dispatch)."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 20
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 16, seed=2000 + n)
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    monkeypatch.setenv("MMHN_PSOLVE_MIN", "1")
+    monkeypatch.setenv("MMHN_WSOLVE", "1")
+    monkeypatch.setenv("MMHN_POISON", "1")
+    e = Engine(n)
+    e.set_cohort(dat)
+    r = e.patient_grads(lt, dp, dm)
+    e.close()
+    np.testing.assert_allclose(r[0], lp, rtol=1e-10)
+    np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
+    rows = [
+        _row(n, range(16), [17, 18, 19], 1),                    # 16 row bits: beyond the window path
+        _row(n, range(15), range(14, 19), 2),                   # kP = 15, kM = 5, one pair
+        _row(n, range(13), range(10, 16), 2),                   # kP = 13, kM = 6, three pairs
+        _row(n, list(range(0, 20, 2)) + [1], range(1, 17, 2), 0),   # kP = 11, kM = 8
+        _row(n, range(10), range(5, 14), 1),                    # kP = 10, kM = 9
+        _row(n, range(9), range(6, 19), 0),                     # kM = 13 rows, pairs
+        _row(n, range(5), range(5, 15), 0),                     # kM = 10 rows, no pair, k = 16: no external bits
+        _row(n, range(10), range(10, 15), 1),                   # k = 16, kP = 10 rows
+        _row(n, range(12), [12, 13], 0),                        # k = 15: too few column bits for the window path
+    ]
+    dat = np.array(rows, dtype=np.int8)
+    res = []
+    for ms in ("1", "0"):
+        monkeypatch.setenv("MMHN_WSOLVE", ms)
+        e = Engine(n)
+        e.set_cohort(dat)
+        res.append(e.patient_grads(lt, dp, dm))
+        e.close()
+    for x, y in zip(*res):
+        assert np.isfinite(x).all()
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
