@@ -41,6 +41,8 @@ struct Desc {
   long long off;       // element offset of this problem's state vectors in the batch buffers
   long long aoff;      // element offset of its gradient work arrays
   long long toff;      // element offset of its per-evaluation tables (k_prep)
+  int wl;              // >= 0: the seeded half of its vectors is stored in the window layout (wlayout.h), index of its WDesc
+  int pad_;
   int8_t ev[32];       // event of bit b
   int8_t cls[32];      // Cls of bit b
   int8_t bitP[32];     // event -> class-P bit or -1
@@ -80,7 +82,7 @@ inline int popc(uint32_t v) { return __builtin_popcount(v); }
 // joint space of `state` (length 2n+1)
 inline Desc make_joint(const int8_t* state, int n) {
   Desc d{};
-  d.mode = JOINT; d.N = n + 1; d.seedbit = -1; d.pset = PS_THETA; d.obs = OBS_JOINT;
+  d.mode = JOINT; d.N = n + 1; d.seedbit = -1; d.pset = PS_THETA; d.obs = OBS_JOINT; d.wl = -1;
   for (int i = 0; i < 32; ++i) { d.bitP[i] = -1; d.bitM[i] = -1; d.ev[i] = 0; d.cls[i] = 0; }
   int k = 0;
   for (int j = 0; j < n; ++j) {
@@ -98,7 +100,7 @@ inline Desc make_joint(const int8_t* state, int n) {
 // single-tumour space of `state` (length n+1, seeding last)
 inline Desc make_single(const int8_t* state, int n, int pset, int obs) {
   Desc d{};
-  d.mode = SINGLE; d.N = n + 1; d.seedbit = -1; d.pset = pset; d.obs = obs;
+  d.mode = SINGLE; d.N = n + 1; d.seedbit = -1; d.pset = pset; d.obs = obs; d.wl = -1;
   for (int i = 0; i < 32; ++i) { d.bitP[i] = -1; d.bitM[i] = -1; d.ev[i] = 0; d.cls[i] = 0; }
   int k = 0;
   for (int j = 0; j <= n; ++j)

@@ -32,6 +32,7 @@
 #include "small.h"
 #include "msolve.h"
 #include "wsolve.h"
+#include "wclass.h"
 #include "sampler.h"
 
 namespace mmhn {
@@ -119,6 +120,7 @@ struct Batch {
   DevArr<int> d_olist;
   // window path (wsolve.h): the same dispatch, 15 / 16 index bits on the chip
   bool wpath = false;
+  bool wdirect = false;          // the consumers read the window layout in place (no conversion to index order)
   std::vector<WDesc> wd;
   DevArr<WDesc> d_wd;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
@@ -456,6 +458,7 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -706,15 +709,17 @@ struct Engine : EngineBase {
       const int nW = (int)b.wd.size();
       double bytes = 0;
       for (const WDesc& w : b.wd) bytes += 0.5 * (double)(1ll << b.dJ[w.prob].k) * sizeof(T);
-      T* yw = tr ? qM.p : piM.p;
+      T* yw = b.wdirect ? y : (tr ? qM.p : piM.p);
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
         const dim3 g((unsigned)std::min(nW, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
         const size_t lds = wsolve_lds<T>();
         if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
         else hipLaunchKernelGGL((k_wsolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
       });
-      hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
-      HIPCHECK(hipGetLastError());
+      if (!b.wdirect) {
+        hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
+        HIPCHECK(hipGetLastError());
+      }
       nold = (int)b.olist.size();
       plist = b.d_olist.p;
       if (nold == 0) return;
@@ -1051,6 +1056,11 @@ struct Engine : EngineBase {
           if (!b.sp_list[w][c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
           up(b.d_sp_list[w][c], b.sp_list[w][c]);
         }
+      // the window layout stays in place: every consumer of the joint vectors reads it there (k_gather_marg / the small-space
+      // kernels, k_eq_flows, k_wclass); MMHN_WSOLVE=2 converts to index order after each solve instead (k_wconvert)
+      b.wdirect = b.wpath && wsolve_mode != 2;
+      for (Desc& dj : b.dJ) dj.wl = -1;
+      if (b.wdirect) for (size_t i = 0; i < b.wd.size(); ++i) b.dJ[b.wd[i].prob].wl = (int)i;
       up(b.d_dJ, b.dJ); up(b.d_dS, b.dS); up(b.d_mapJ, b.mapJ); up(b.d_mapS, b.mapS);
       up(b.d_lmapJ, b.lmapJ); up(b.d_lmapS, b.lmapS);
       up(b.d_ptoff, b.ptoff); up(b.d_ptiles, b.ptiles); up(b.d_mapX, b.mapX);
@@ -1066,7 +1076,7 @@ struct Engine : EngineBase {
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS);
       mZ = std::max<size_t>(mZ, (size_t)zarena_elems((long long)b.dJ.size(), b.asize, N));
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
-      if (b.mpath || b.wpath) mvM = std::max(mvM, b.vecJ);
+      if (b.mpath || (b.wpath && !b.wdirect)) mvM = std::max(mvM, b.vecJ);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
     pi.alloc(mvJ); qJ.alloc(mvJ);
@@ -1116,7 +1126,7 @@ struct Engine : EngineBase {
       HIPCHECK(hipStreamWaitEvent(sd, ev_fork[which], 0));
     }
     fork_recorded[which] = false;
-#define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, b.d_dJ.p, pi.p, links.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
+#define SP_TAIL b.d_pats.p, b.d_dS.p, d_par.p, d_perm.p, d_lvl.p, b.d_dJ.p, b.d_wd.p, pi.p, links.p, pS.p, qS.p, GS.p, bmS.p, dots.p, lp.p
     auto big_class = [&]() {
       if (!n2) return;
       const size_t lds = (spatient_lds<T>(N, mk2) + 15) / 16 * 16;
@@ -1212,7 +1222,7 @@ struct Engine : EngineBase {
       if (!fused_small) zero(rhsS.p, b.vecS);
       if (nJ && !fused_small) {                           // (the small-space kernels read pi themselves and write the links)
         hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.paired.size(), 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
-                           b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_paired.p);
+                           b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_paired.p, b.d_wd.p);
         HIPCHECK(hipGetLastError());
       }
       if (fused_small) {
@@ -1254,10 +1264,14 @@ struct Engine : EngineBase {
             // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
             const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
             timed(MMHN_K_PCLASS, mbytes, [&]() {
+              if (b.wdirect) {                                                  // window-layout problems: both classes, two reads
+                const int nW = (int)b.wd.size();
+                hipLaunchKernelGGL((k_wclass<T>), dim3((unsigned)std::min(nW, n_cu)), dim3(WROWS), wclass_lds<T>(), stream, b.d_dJ.p, b.d_wd.p, nW, pi.p, qJ.p, Abuf.p);
+              }                                                                 // (k_pclass skips them; its SPLIT form still runs their eq flows)
               if (nJ <= prep_split_max)
-                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 3), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 3), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
               else
-                hipLaunchKernelGGL((k_pclass<T, false>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+                hipLaunchKernelGGL((k_pclass<T, false>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
             });
             if (!b.mapX.empty())
               hipLaunchKernelGGL((k_class_marg<T>), dim3((unsigned)b.mapX.size()), dim3(CMB), 2 * sizeof(T) << TB, stream,
@@ -1270,7 +1284,7 @@ struct Engine : EngineBase {
           // (its own launch: folded into the workgroups of k_pclass it cost more than the launch - k_pclass 20.5 -> 21.9 ms
           // on the bench cohort, the LUAD evaluation +25 us; short launches run it as workgroups of their own in k_pclass)
           if (!(per_patient && nJ <= prep_split_max)) {
-            hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, pi.p, qJ.p, Abuf.p);
+            hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
             HIPCHECK(hipGetLastError());
           }
           launch_grad_rows(b.d_dJ.p, nJ, b.maxkcJ, Abuf.p, nullptr, nullptr, GJ.p, -1, b.d_grcJ, DJ.p, gjs);
@@ -1629,7 +1643,7 @@ struct Engine : EngineBase {
     hipLaunchKernelGGL((k_class_marg<T>), dim3(m.ntiles), dim3(CMB), 2 * sizeof(T) << TB, stream, m.dd.p, m.map.p,
                        m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, m.a.p, m.b.p, m.c.p);
+    hipLaunchKernelGGL((k_eq_flows<T>), dim3(1), dim3(BLOCK), 0, stream, m.dd.p, static_cast<const WDesc*>(nullptr), m.a.p, m.b.p, m.c.p);
     HIPCHECK(hipGetLastError());
     for (int kd = 0; kd < 3; ++kd) {
       std::vector<int2> gc = grad_chunks(std::vector<Desc>{m.d}, kd);

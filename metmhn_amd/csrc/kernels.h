@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "desc.h"
+#include "wlayout.h"
 
 namespace mmhn {
 
@@ -84,13 +85,6 @@ __device__ __forceinline__ bool seed_move_possible(uint32_t lone, uint32_t pairP
 // so a tile gets 1/(D - diag Q) from two small table reads instead of a 2^k vector.
 // ------------------------------------------------------------------------------------
 __host__ __device__ inline long long rate_table_size(int k) { return (long long)k * k + 2ll * k * 64; }
-__host__ __device__ inline int popc32(uint32_t v) {
-#ifdef __HIP_DEVICE_COMPILE__
-  return __popc(v);
-#else
-  return __builtin_popcount(v);
-#endif
-}
 __host__ __device__ inline long long table_size(const Desc& d) {
   long long s = rate_table_size(d.k);
   if (d.mode == JOINT && d.seedbit >= 0) s += (1ll << popc32(d.maskP)) + (1ll << popc32(d.maskM)) + (1ll << popc32(d.pairP));
@@ -813,26 +807,6 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
 constexpr int TSB = MMHN_TSB;                // threads per workgroup of k_tsolve / k_psolve
 constexpr int TSB_WPE = TSB == 1024 ? 8 : 4; // waves per SIMD the register budget is sized for (two workgroups per CU)
 
-__device__ __forceinline__ uint32_t pext32(uint32_t x, uint32_t mask) {
-  uint32_t out = 0, pos = 0;
-  while (mask) {
-    const uint32_t low = mask & (0u - mask);
-    if (x & low) out |= 1u << pos;
-    ++pos;
-    mask ^= low;
-  }
-  return out;
-}
-__device__ __forceinline__ uint32_t pdep32(uint32_t v, uint32_t mask) {
-  uint32_t out = 0;
-  while (mask) {
-    const uint32_t low = mask & (0u - mask);
-    if (v & 1u) out |= low;
-    v >>= 1;
-    mask ^= low;
-  }
-  return out;
-}
 
 // LIDGV: 1/(D - diag Q) comes from the vector `lidg` (API path, single-tumour spaces);
 // otherwise from the class tables of k_prep (joint spaces with seeding: engine path).
@@ -2116,7 +2090,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
                                                        const Desc* __restrict__ dS,
                                                        const Params<T>* __restrict__ par,
                                                        const T* __restrict__ pi, T* rhsS, JLink<T>* links,
-                                                       const int* __restrict__ paired) {
+                                                       const int* __restrict__ paired, const WDesc* __restrict__ wds) {
   __shared__ Desc djs;                                     // (the descriptor loops below must not be chains of global loads)
   const PatRec pr = pats[paired[blockIdx.x]];              // grid.x = the paired patients of the batch only
   const int part = blockIdx.y;
@@ -2137,8 +2111,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
   const uint32_t half = 1u << (ksS - 1);
   const T c = obs_const(dj, par[PS_THETA], part);
   if (writes_link) { links[pr.j].soff[part] = offS; links[pr.j].sk[part] = ksS; links[pr.j].cst[part] = c; }
+  // (window-layout problem, wlayout.h: part 0 frees the M bits, part 1 the P bits)
+  const bool free_is_row = dj.wl >= 0 && (wds[dj.wl].majP != 0) == (part == 1);
   for (uint32_t e = blockIdx.z * BLOCK + threadIdx.x; e < half; e += gridDim.z * BLOCK) {
-    const uint32_t x = pdep32(e, free_) | fixed;
+    const long long x = dj.wl >= 0 ? wpos_marg<T>(wds[dj.wl], dj.k, free_is_row, e) : (long long)(pdep32(e, free_) | fixed);
     rhsS[offS + e] = 0;
     rhsS[offS + half + e] = c * pi[dj.off + x];
   }
@@ -2249,7 +2225,7 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
   const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x);
   const Desc& d = dJ[map[blk].x];
   const uint32_t H = (uint32_t)map[blk].y;
-  if (d.seedbit < 0) return;
+  if (d.seedbit < 0 || d.wl >= 0) return;
   const int k = d.k;
   const int t = k < TB ? k : TB;
   const uint32_t nelem = 1u << t, tmask = nelem - 1;
@@ -2383,8 +2359,8 @@ __global__ __launch_bounds__(CMB) void k_class_marg(const Desc* __restrict__ dJ,
 //   slot 1 + l   p[x0] q[x0 | pair_l]          (pair_l not in e)
 //   slot ke + 1  p[x0] q[x0 | seedbit]         (0 if seeding inactive)
 template <typename T>
-__device__ __forceinline__ void eq_flows_body(const Desc& d, const T* __restrict__ p, const T* __restrict__ q, T* A, int tid,
-                                              int nthreads) {
+__device__ __forceinline__ void eq_flows_body(const Desc& d, const WDesc* __restrict__ wds, const T* __restrict__ p,
+                                              const T* __restrict__ q, T* A, int tid, int nthreads) {
   const int ke = __popc(d.pairP);
   T* out = A + d.aoff + class_block_size(__popc(d.maskP)) + class_block_size(__popc(d.maskM));
   const long long items = (long long)(ke + 2) << ke;
@@ -2400,16 +2376,18 @@ __device__ __forceinline__ void eq_flows_body(const Desc& d, const T* __restrict
       const uint32_t bp = pdep32(1u << (slot - 1), d.pairP);
       v = (x0 & bp) ? T(0) : p[d.off + x0] * q[d.off + (x0 | bp | (bp << 1))];
     } else {
-      v = d.seedbit >= 0 ? p[d.off + x0] * q[d.off + (x0 | (1u << d.seedbit))] : T(0);
+      // (the seeded half of a window-layout problem is not in index order)
+      const long long xs = d.wl >= 0 ? (1ll << (d.k - 1)) + wpos_nat<T>(wds[d.wl], x0) : (long long)(x0 | (1u << d.seedbit));
+      v = d.seedbit >= 0 ? p[d.off + x0] * q[d.off + xs] : T(0);
     }
     out[it] = v;
   }
 }
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_eq_flows(const Desc* __restrict__ dJ,
+__global__ __launch_bounds__(BLOCK) void k_eq_flows(const Desc* __restrict__ dJ, const WDesc* __restrict__ wds,
                                                     const T* __restrict__ p,
                                                     const T* __restrict__ q, T* A) {
-  eq_flows_body(dJ[blockIdx.x], p, q, A, (int)threadIdx.x, BLOCK);
+  eq_flows_body(dJ[blockIdx.x], wds, p, q, A, (int)threadIdx.x, BLOCK);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2440,7 +2418,7 @@ __device__ __forceinline__ uint32_t low_bits(uint32_t m, int n) {
 }
 
 template <typename T, bool SPLIT = false>
-__global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, const T* __restrict__ p,
+__global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, const WDesc* __restrict__ wds, const T* __restrict__ p,
                                                    const T* __restrict__ q, T* A) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* pt = reinterpret_cast<T*>(smem);
@@ -2448,9 +2426,9 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   const Desc& d = dJ[blockIdx.x];
   // SPLIT (gridDim.y == 3): a workgroup per class pass and one for the eq block's flows (k_eq_flows) - short launches,
   // whose length is one workgroup's chain
-  if (SPLIT && blockIdx.y == 2) { eq_flows_body(d, p, q, A, (int)threadIdx.x, CMB); return; }
+  if (SPLIT && blockIdx.y == 2) { eq_flows_body(d, wds, p, q, A, (int)threadIdx.x, CMB); return; }
   const int seedbit = d.seedbit;
-  if (seedbit < 0) return;
+  if (seedbit < 0 || d.wl >= 0) return;                   // (window-layout problems: k_wclass)
   const int k = d.k;
   const uint32_t sbm = 1u << seedbit;
   const uint32_t allbits = (k >= 32 ? 0xffffffffu : ((1u << k) - 1u)) & ~sbm;

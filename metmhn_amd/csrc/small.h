@@ -44,7 +44,7 @@ template <typename T, int SPB, int PPB, bool PAIR = false>
 __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int npl, const PatRec* __restrict__ pats, const Desc* __restrict__ dS,
                                               const Params<T>* __restrict__ par,
                                               const uint16_t* __restrict__ perm, const int* __restrict__ lvl,
-                                              const Desc* __restrict__ dJ, const T* __restrict__ pi, JLink<T>* __restrict__ links,
+                                              const Desc* __restrict__ dJ, const WDesc* __restrict__ wds, const T* __restrict__ pi, JLink<T>* __restrict__ links,
                                               T* __restrict__ pS, T* __restrict__ qS,
                                               T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots,
                                               double* __restrict__ lp, int maxk, int N, int with_grad, int block) {
@@ -209,7 +209,8 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
   // :573-575, :617-618) - taken straight from the joint solution, no launch and no buffer in between; D is constant on
   // those states (obs_const: same factors in the same order) and is also the constant of the joint adjoint's
   // right-hand side, so the links are written here
-  struct Marg { T c; uint32_t fixed, free_, half; long long joff; };
+  // (wl >= 0: the joint solution lives in the window layout, wlayout.h)
+  struct Marg { T c; uint32_t fixed, free_, half; long long joff; int wl, kj; bool free_is_row; };
   auto marg_of = [&](int part, int k) -> Marg {
     const Desc* dj = dJ + pr.j;
     const Params<T>& PT = par[PS_THETA];
@@ -230,10 +231,14 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
     m.free_ = part == 0 ? dj->maskM : dj->maskP;
     m.half = 1u << (k - 1);
     m.joff = dj->off;
+    m.wl = dj->wl; m.kj = kj;
+    m.free_is_row = m.wl >= 0 && (wds[m.wl].majP != 0) == (part == 1);      // part 0 frees the M bits, part 1 the P bits
     return m;
   };
   auto marg_rhs = [&](const Marg& m, uint32_t x) -> T {
-    return x < m.half ? T(0) : m.c * pi[m.joff + (pdep32(x - m.half, m.free_) | m.fixed)];
+    if (x < m.half) return T(0);
+    if (m.wl >= 0) return m.c * pi[m.joff + wpos_marg<T>(wds[m.wl], m.kj, m.free_is_row, x - m.half)];
+    return m.c * pi[m.joff + (pdep32(x - m.half, m.free_) | m.fixed)];
   };
   Marg mg0{}, mg1{};
 
@@ -453,10 +458,11 @@ __device__ __forceinline__ void spatient_body(const int* __restrict__ plist, int
 }
 
 #define SPATIENT_PARAMS const PatRec* __restrict__ pats, const Desc* __restrict__ dS, const Params<T>* __restrict__ par, \
-    const uint16_t* __restrict__ perm, const int* __restrict__ lvl, const Desc* __restrict__ dJ, const T* __restrict__ pi, \
+    const uint16_t* __restrict__ perm, const int* __restrict__ lvl, const Desc* __restrict__ dJ, const WDesc* __restrict__ wds, \
+    const T* __restrict__ pi, \
     JLink<T>* __restrict__ links, T* __restrict__ pS, \
     T* __restrict__ qS, T* __restrict__ GS, T* __restrict__ bmS, T* __restrict__ dots, double* __restrict__ lp
-#define SPATIENT_ARGS pats, dS, par, perm, lvl, dJ, pi, links, pS, qS, GS, bmS, dots, lp
+#define SPATIENT_ARGS pats, dS, par, perm, lvl, dJ, wds, pi, links, pS, qS, GS, bmS, dots, lp
 
 // one size class per launch (the 1024-thread class)
 template <typename T, int SPB, int PPB, bool PAIR = false>

@@ -1220,14 +1220,25 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
         _row(n, range(10), range(10, 15), 1),                   # k = 16, kP = 10 rows
         _row(n, range(12), [12, 13], 0),                        # k = 15: too few column bits for the window path
     ]
-    dat = np.array(rows, dtype=np.int8)
-    res = []
-    for ms in ("1", "0"):
-        monkeypatch.setenv("MMHN_WSOLVE", ms)
-        e = Engine(n)
-        e.set_cohort(dat)
-        res.append(e.patient_grads(lt, dp, dm))
-        e.close()
-    for x, y in zip(*res):
-        assert np.isfinite(x).all()
-        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+    # (a) mixed shapes: the single-tumour spaces of the large rows exceed a tile -> staged marginal kernels (k_gather_marg);
+    # (b) rows whose marginal spaces fit a tile -> the small-space kernels read the window layout (small.h);
+    # each with the layout read in place ("1"), converted to index order after every solve ("2"), and without it ("0")
+    small = [
+        _row(n, range(5), range(5, 15), 0),                     # kM = 10 rows, kP = 5
+        _row(n, range(10), range(10, 15), 1),                   # kP = 10 rows
+        _row(n, range(10), range(8, 14), 2),                    # kP = 10, kM = 6, two pairs
+        _row(n, range(3, 9), range(0, 11), 0),                  # kM = 11 rows, six pairs
+    ]
+    for cohort in (rows, small):
+        dat = np.array(cohort, dtype=np.int8)
+        res = []
+        for ms in ("1", "2", "0"):
+            monkeypatch.setenv("MMHN_WSOLVE", ms)
+            e = Engine(n)
+            e.set_cohort(dat)
+            res.append(e.patient_grads(lt, dp, dm))
+            e.close()
+        for r1 in res[:2]:
+            for x, y in zip(r1, res[2]):
+                assert np.isfinite(x).all()
+                np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
