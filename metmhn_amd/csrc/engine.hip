@@ -386,7 +386,8 @@ struct Engine : EngineBase {
   int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
                                 // second implementation, measured alternative - DESIGN.md 6); default: the tile kernels (k_psolve2)
   int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
-  int wsolve_mode = 0;          // MMHN_WSOLVE=1: joint solves of per-patient batches in the window layout (wsolve.h)
+  int wsolve_mode = 1;          // joint solves of per-patient batches in the window layout (wsolve.h); MMHN_WSOLVE=0: the tile
+                                // kernels (k_psolve2) for every problem, 2: window solves converted back to index order
   DevArr<T> piM, qM;            // matrix / window path: solutions in their own layout
   DevArr<uint16_t> d_rowT, d_rankT;
   DevArr<MUnit> d_units;
@@ -439,7 +440,7 @@ struct Engine : EngineBase {
       if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
       if (const char* ms = std::getenv("MMHN_MSOLVE")) msolve_mode = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
-      if (wsolve_mode) msolve_mode = 0;
+      if (msolve_mode) wsolve_mode = 0;
       if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
       std::vector<uint16_t> rt(MROWS), rk(MROWS);
       matrix_rows(rt.data(), rk.data());

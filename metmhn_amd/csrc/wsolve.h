@@ -22,11 +22,13 @@
 // ever waits for another lane of its wave, and no level ever idles except while the pipeline fills and drains.
 // oracle/wschedule.py is a scalar model of exactly this schedule (tests/test_oracle_golden.py runs it).
 //
-// Storage of the seeded half ("window layout"):
+// Storage of the seeded half ("window layout", wlayout.h):
 //     position(S, T) = (((Sigma * H + beta) * 1024 + rho(w, l)) * NC + c,   T = c | beta << RB | Tx << (RB + HB),
 //     Sigma = Tx | Sx << nXc,  S = l | w << 6 | Sx << 10,
 // rho sorts the rows of a block by lane-level so that the lanes of a wave which work on the same external index
 // (= the same lane-level) touch one contiguous run of memory.  The seed = 0 half keeps its natural positions.
+// (Measured and dropped: a block as two planes of 16 bytes per row - no line requested by two instructions, but runs
+// half as long: adjoint 18.6 -> 22.9 ms; a one-dword LDS-DMA touch of the next step's external rows: +2.5 / +6 ms.)
 #pragma once
 #include "msolve.h"
 #include "wlayout.h"
@@ -112,7 +114,7 @@ struct WLds {
   static constexpr int e0 = Er + WKR * 32;                              // [2^ke] eq-block solution
   static constexpr int se = e0 + (1 << MKE);                            // [2^ke] forward: seeding inflow of eq state e
   static constexpr int end = se + (1 << MKE);
-  static constexpr size_t bytes = (size_t)end * sizeof(T) + 64 * sizeof(int);
+  static constexpr size_t bytes = (size_t)end * sizeof(T) + 64 * sizeof(int) + 256;   // + landing area of the prefetch loads
 };
 template <typename T>
 constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
@@ -153,6 +155,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   T* const e0 = lds + L::e0;
   T* const se = lds + L::se;
   int* const bits = reinterpret_cast<int*>(lds + L::end);      // [0..15] rb, [16..31] cb, [32..47] prt
+  auto* const junk = reinterpret_cast<__attribute__((address_space(3))) void*>(
+      (__attribute__((address_space(3))) unsigned char*)(smem) + (size_t)L::end * sizeof(T) + 64 * sizeof(int));
   T* const thc = ring;                                         // [k][k] effects between index bits: only while the tables are built
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     // Sigma: external index (0 on a lane that is outside the pipeline), soff: byte offset of its blocks (beyond the
     // buffer on such a lane: its stores are dropped, its loads return zeros), rcb: offset of its column tables
     uint32_t Sigma = 0, rcb = 0, goff = 0, soff = OOB;
+    int cur_sig = 0;
     T cL[WLB], dRv = T(1);
     uint32_t hitT = 0xffffffffu, hitE = 0;
     // (thread-derived values are re-derived from an opaque copy of the thread id inside every step / pass: hipcc would
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
       const int Sg = sig - (TR ? WLB - __popc(ln) : __popc(ln));
+      cur_sig = sig;
       const bool act = (unsigned)Sg < NXS;
       Sigma = act ? (TR ? NXS - 1u - (uint32_t)Sg : (uint32_t)Sg) : 0u;
       const uint32_t Sx = Sigma >> nXc;
@@ -464,6 +470,26 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         }
       }
       Wd[beta] = Y;
+#ifdef MMHN_W_PREFETCH       // (measured: +2.5 / +6 ms per solve - the memory system is bound by its request rate)
+      // the external blocks of the NEXT step: one dword of each row is requested now and lands in a junk area of LDS (no
+      // register, nothing waits for it) - it pulls the lines into L2 a step ahead, the step's own loads then find them there
+      {
+        uint32_t g2 = goff, S2 = Sigma;
+        bool a2 = soff != OOB;
+        constexpr uint32_t boff2 = (uint32_t)(TR ? (BI + 1 < H ? beta - 1 : H - 1) : (BI + 1 < H ? beta + 1 : 0)) * BLKB;
+        if constexpr (BI + 1 == H) {                           // first block of the next window pass
+          const int Sg2 = cur_sig + 1 - (TR ? WLB - __popc(ln) : __popc(ln));
+          a2 = (unsigned)Sg2 < NXS;
+          S2 = a2 ? (TR ? NXS - 1u - (uint32_t)Sg2 : (uint32_t)Sg2) : 0u;
+          g2 = (S2 << BSH) + voff;
+        }
+        for (int j = 0; j < nX; ++j) {
+          const bool has = TR ? !((S2 >> j) & 1u) : ((S2 >> j) & 1u);
+          const uint32_t o2 = (has && a2) ? (g2 ^ (1u << (j + BSH))) : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, junk, 4, (int)o2, (int)boff2, 0, 0);
+        }
+      }
+#endif
       if (TR ? wv != 0 : wv != WROWS / 64 - 1) {               // some wave above / below reads it
         T* ws = ring + (uint32_t)gpar * (NC * WROWS);
         const Raw r = __builtin_bit_cast(Raw, Y);
