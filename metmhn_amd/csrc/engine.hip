@@ -121,8 +121,10 @@ struct Batch {
   // window path (wsolve.h): the same dispatch, 15 / 16 index bits on the chip
   bool wpath = false;
   bool wdirect = false;          // the consumers read the window layout in place (no conversion to index order)
-  std::vector<WDesc> wd;
+  std::vector<WDesc> wd;         // sorted by shape; the state vectors of consecutive entries lie back to back
   DevArr<WDesc> d_wd;
+  std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
+  DevArr<WChain> d_wchains;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
@@ -385,6 +387,7 @@ struct Engine : EngineBase {
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
   int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
                                 // second implementation, measured alternative - DESIGN.md 6); default: the tile kernels (k_psolve2)
+  int wsolve_chain = 1;         // MMHN_WSOLVE_CHAIN=0: every window problem its own chain (the pipeline drains between patients)
   int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
   int wsolve_mode = 1;          // joint solves of per-patient batches in the window layout (wsolve.h); MMHN_WSOLVE=0: the tile
                                 // kernels (k_psolve2) for every problem, 2: window solves converted back to index order
@@ -442,6 +445,7 @@ struct Engine : EngineBase {
       if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
       if (msolve_mode) wsolve_mode = 0;
       if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
+      if (const char* ms = std::getenv("MMHN_WSOLVE_CHAIN")) wsolve_chain = std::atoi(ms);
       std::vector<uint16_t> rt(MROWS), rk(MROWS);
       matrix_rows(rt.data(), rk.data());
       d_rowT.alloc(MROWS); d_rankT.alloc(MROWS);
@@ -712,10 +716,11 @@ struct Engine : EngineBase {
       for (const WDesc& w : b.wd) bytes += 0.5 * (double)(1ll << b.dJ[w.prob].k) * sizeof(T);
       T* yw = b.wdirect ? y : (tr ? qM.p : piM.p);
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-        const dim3 g((unsigned)std::min(nW, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
+        const int nch = (int)b.wchains.size();
+        const dim3 g((unsigned)std::min(nch, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
         const size_t lds = wsolve_lds<T>();
-        if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
-        else hipLaunchKernelGGL((k_wsolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, nW, yw, tabJ.p, links.p, qS.p);
+        if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p);
+        else hipLaunchKernelGGL((k_wsolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p);
       });
       if (!b.wdirect) {
         hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
@@ -982,8 +987,33 @@ struct Engine : EngineBase {
           b.wd.push_back(make_wdesc<T>(b.dJ[pj], (int)pj));
         }
         if (b.wd.empty()) b.wpath = false;
+      }
+      b.wchains.clear();
+      if (b.wpath) {
+        // chains (wsolve.h): the window problems sorted by shape, their vectors laid out in that order (the offsets are
+        // the engine's own business: every kernel goes through Desc::off), then cut into about one run per workgroup
+        std::stable_sort(b.wd.begin(), b.wd.end(), [](const WDesc& x, const WDesc& y) { return x.kR != y.kR ? x.kR < y.kR : x.kC < y.kC; });
+        long long off = 0;
+        for (const WDesc& w : b.wd) { b.dJ[w.prob].off = off; off += 1ll << b.dJ[w.prob].k; }
+        for (int pj : b.olist) { b.dJ[pj].off = off; off += 1ll << b.dJ[pj].k; }
+        REQUIRE(off == b.vecJ, "window path: offsets of the joint problems do not add up");
+        const int nW = (int)b.wd.size();
+        const int groups = std::max(1, wsolve_wgs > 0 ? wsolve_wgs : n_cu);
+        const int per = (nW + groups - 1) / groups;
+        for (int i0 = 0; i0 < nW;) {
+          const WDesc& w = b.wd[i0];
+          const int k = b.dJ[w.prob].k;
+          // a chain keeps two patients' tables alive at once: it needs 2^nX > 6 passes per patient; its span must stay
+          // below 2 GB (32-bit buffer offsets)
+          const int maxlen = (w.nXc + w.nXr >= 3 && wsolve_chain) ? (int)std::min<long long>(per, (1ll << 31) / ((long long)sizeof(T) << k) - 1) : 1;
+          int len = 1;
+          while (len < maxlen && i0 + len < nW && b.wd[i0 + len].kR == w.kR && b.wd[i0 + len].kC == w.kC && (i0 + len) % per != 0) ++len;
+          b.wchains.push_back(WChain{i0, len});
+          i0 += len;
+        }
         up(b.d_wd, b.wd);
         up(b.d_olist, b.olist);
+        up(b.d_wchains, b.wchains);
       }
       b.mapX.clear();
       for (const int2& m : b.mapJ) {

@@ -100,21 +100,45 @@ __global__ void k_lane_moves(int* out) {
   out[5 * 64 + lane] = lane_nbr32<5, TR>(lane, lane);
 }
 
+// A CHAIN is a run of consecutive entries of the (shape-sorted) WDesc list that have the same shape (kR, kC) and whose state
+// vectors lie back to back in memory: one workgroup streams through it without draining its pipeline between patients -
+// the lanes of low lane-level start on patient j + 1 while the lanes of high lane-level still finish patient j (a lane of
+// lane-level m works on window pass sig - m of the chain, pass = patient * 2^nX + external index).
+struct WChain { int start, count; };
+
+template <typename T>
+struct WPInfo {                      // what a lane needs to know about the patient it is working on (two live per workgroup)
+  long long droff;                   // element offset (in the table buffer) of the row-class diagonal table
+  long long soff[2];                 // transposed: start of the upper half of q_S of the row part / column part, -1: none
+  T cst[2];                          //             its constant (JLink)
+  uint32_t pairRowC, loneRowC;       // forward: compact row bits with / without a partner slot
+  int prt[16];                       //          column bit of the partner of row bit i
+};
+
 template <typename T>
 struct WLds {
   using C = WCfg<T>;
-  static constexpr int NC = 1 << C::RB, WIN = 1 << (C::RB + C::HB);
-  static constexpr int RCS = (1 << C::KC) + (C::PAD << (C::KC - C::RB - C::HB));   // padded length of one table over the column sets
+  static constexpr int NC = 1 << C::RB, WB = C::RB + C::HB, WIN = 1 << WB, NXCM = C::KC - WB;
+  // rates of the column-class events, only for the column sets that do not contain the event (half of them):
+  //   bit b < WB (inside a window): [external column setting Tx][window setting with bit b squeezed out] - SZLO entries
+  //   bit b >= WB (external):       [Tx with bit b - WB squeezed out][window setting]                     - SZHI entries
+  static constexpr int LOS = WIN / 2 + C::PAD, HIS = WIN + C::PAD;     // row strides (the lanes of a wave differ in Tx: banks)
+  static constexpr int SZLO = (1 << NXCM) * LOS, SZHI = (NXCM > 0 ? (1 << (NXCM - 1)) : 1) * HIS;
+  static constexpr int oRh = 0;
+  static constexpr int oDC = oRh + WB * SZLO + NXCM * SZHI;            // [Tx][window setting] column part of the diagonal
+  static constexpr int oLr = oDC + (1 << NXCM) * HIS;                  // [WKR][64] row-bit rate: product over the lane bits
+  static constexpr int oUr = oLr + WKR * 64;                           // [WKR][16] ... base rate and the wave bits
+  static constexpr int oEr = oUr + WKR * 16;                           // [WKR][32] ... the external row bits
+  static constexpr int oSe = oEr + WKR * 32;                           // [2^ke] forward: seeding inflow of eq state e
+  static constexpr int TABSZ = (oSe + (1 << MKE) + 3) / 4 * 4;         // one patient's tables
   static constexpr int ring = 0;                                        // [2][NC * sizeof(T) / 16][WROWS] 16-byte pieces
-  static constexpr int Rc = ring + 2 * NC * WROWS;                      // [KC][RCS] rate of column bit b from column set T
-  static constexpr int dC = Rc + C::KC * RCS;                           // [RCS] column part of the diagonal
-  static constexpr int Lr = dC + RCS;                                   // [WKR][64] row-bit rate: product over the lane bits
-  static constexpr int Ur = Lr + WKR * 64;                              // [WKR][16] ... base rate and the wave bits
-  static constexpr int Er = Ur + WKR * 16;                              // [WKR][32] ... the external row bits
-  static constexpr int e0 = Er + WKR * 32;                              // [2^ke] eq-block solution
-  static constexpr int se = e0 + (1 << MKE);                            // [2^ke] forward: seeding inflow of eq state e
-  static constexpr int end = se + (1 << MKE);
-  static constexpr size_t bytes = (size_t)end * sizeof(T) + 64 * sizeof(int) + 256;   // + landing area of the prefetch loads
+  static constexpr int tab0 = ring + 2 * NC * WROWS;                    // two patients' tables
+  static constexpr int end = tab0 + 2 * TABSZ;
+  // while a patient enters or leaves the pipeline the ring is dead: the effect table thc [k][k] and the eq-block
+  // solution e0 [2^ke] live there
+  static constexpr int thc = ring, e0 = ring + (MAXK * MAXK + 3) / 4 * 4;
+  static constexpr size_t bytes = (size_t)end * sizeof(T) + 2 * sizeof(WPInfo<T>) + 64;
+  static_assert(e0 + (1 << MKE) <= tab0, "event scratch fits the ring");
 };
 template <typename T>
 constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
@@ -124,19 +148,20 @@ constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
 //   forward: rhs = E0 e_0 (the seed = 0 lattice over the paired events is solved first, seeding carries it into
 //            the seeded half);  transposed: rhs = D_obs * scatter(q_S) from `links` (likelihood.py:573-575,
 //            617-618), the seed = 0 lattice follows the seeded half.
-// Persistent: workgroup b takes problems b, b + gridDim.x, ...
+// Persistent: workgroup b takes chains b, b + gridDim.x, ...
 // ------------------------------------------------------------------------------------
 template <typename T, bool TR>
-__global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs, const WDesc* __restrict__ wds, int nw,
+__global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs, const WDesc* __restrict__ wds,
+                                                  const WChain* __restrict__ chains, int nchains,
                                                   T* y, const T* __restrict__ tab,
                                                   const JLink<T>* __restrict__ links, const T* __restrict__ qS) {
   using C = WCfg<T>;
   using L = WLds<T>;
-  constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, WB = RB + HB, WIN = 1 << WB, PAD = C::PAD, RCS = L::RCS;
+  constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, WB = RB + HB, WIN = 1 << WB;
+  constexpr int LOS = L::LOS, HIS = L::HIS, SZLO = L::SZLO, SZHI = L::SZHI;
   constexpr int QE = 16 / (int)sizeof(T);                      // elements of a 16-byte piece
   constexpr int NQ = NC / QE;                                  // pieces of a block row (2)
   typedef T VecT __attribute__((ext_vector_type(NC)));
-  typedef T QT __attribute__((ext_vector_type(QE)));
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   struct Raw { u32x4 q[NQ]; };
   static_assert(sizeof(Raw) == sizeof(VecT) && NQ == 2, "a row of a block is two 16-byte accesses");
@@ -147,80 +172,46 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   extern __shared__ __align__(16) unsigned char smem[];
   T* const lds = reinterpret_cast<T*>(smem);
   T* const ring = lds + L::ring;
-  T* const Rc = lds + L::Rc;
-  T* const dCt = lds + L::dC;
-  T* const Lr = lds + L::Lr;
-  T* const Ur = lds + L::Ur;
-  T* const Er = lds + L::Er;
+  T* const thc = lds + L::thc;
   T* const e0 = lds + L::e0;
-  T* const se = lds + L::se;
-  int* const bits = reinterpret_cast<int*>(lds + L::end);      // [0..15] rb, [16..31] cb, [32..47] prt
-  auto* const junk = reinterpret_cast<__attribute__((address_space(3))) void*>(
-      (__attribute__((address_space(3))) unsigned char*)(smem) + (size_t)L::end * sizeof(T) + 64 * sizeof(int));
-  T* const thc = ring;                                         // [k][k] effects between index bits: only while the tables are built
-  const int tid = threadIdx.x, lane = tid & 63;
+  WPInfo<T>* const pinfo = reinterpret_cast<WPInfo<T>*>(lds + L::end);
+  const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = TR ? WLB - __popc(lane) : __popc(lane);        // lane-level: windows this lane runs behind
   const int lam = TR ? WWB - __popc(wv) : __popc(wv);          // wave-level: blocks this wave runs behind
-  const uint32_t voff = wrho((uint32_t)wv, (uint32_t)lane) * (uint32_t)sizeof(VecT);
-  auto rcidx = [](uint32_t Tc) -> uint32_t { return Tc + (Tc >> WB) * PAD; };
+  // (thread-derived values are re-derived from an opaque copy of the thread id inside every step / pass: hipcc would
+  // otherwise hoist a dozen loop-invariant LDS addresses out of the step loop and spill them)
+  auto opaque_tid = [&]() -> uint32_t { uint32_t t = (uint32_t)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+  // a column set that does not contain bit b, with bit b squeezed out
+  auto squeeze = [](uint32_t v, int b) -> uint32_t { return ((v >> (b + 1)) << b) | (v & ((1u << b) - 1u)); };
+  auto deskew = [&]() { for (int s = lam; s < WWB; ++s) lds_barrier(); };
+  auto reskew = [&]() { for (int s = 0; s < lam; ++s) lds_barrier(); };
 
-  for (int it = blockIdx.x; it < nw; it += gridDim.x) {
-    const WDesc& wd = wds[it];
-    const int prob = sgpr(wd.prob);
-    const Desc& d = descs[prob];
-    const int k = sgpr(d.k), kR = sgpr(wd.kR), kC = sgpr(wd.kC), nXc = sgpr(wd.nXc), nXr = sgpr(wd.nXr);
+  STAMP_DECL;
+  for (int ci = blockIdx.x; ci < nchains; ci += gridDim.x) {
+    STAMP_START;
+    const int first = sgpr(chains[ci].start), npat = sgpr(chains[ci].count);
+    const WDesc& w0 = wds[first];
+    const Desc& d0 = descs[w0.prob];
+    const int k = sgpr(d0.k), kR = sgpr(w0.kR), kC = sgpr(w0.kC), nXc = sgpr(w0.nXc), nXr = sgpr(w0.nXr);
     const int nX = nXc + nXr;
-    const bool majP = sgpr(wd.majP) != 0;
-    const long long base = sgpr64(d.off), toff = sgpr64(d.toff);
     const int seedb = k - 1;
-    const T* dP = tab + toff + rate_table_size(k);
-    const T* dM = dP + (1ll << __popc(sgpr(d.maskP)));
-    const T* dRg = majP ? dP : dM;
-    const T* dCg = majP ? dM : dP;
     const long long half = 1ll << (k - 1);
-    T* const ym = y + base + half;                             // seeded half, window layout
-    __syncthreads();                                           // previous problem done with the tables and the ring
-    {
-      const T* src = tab + toff;
-      for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
-      if (tid < 16) bits[tid] = wd.rb[tid];
-      else if (tid < 32) bits[tid] = wd.cb[tid - 16];
-      else if (tid < 48) bits[tid] = wd.prt[tid - 32];
-    }
-    __syncthreads();
-    // ---- tables: rates of the column-class events from every column set; the row-class rates as three factors
-    for (uint32_t e = tid; e < ((uint32_t)kC << kC); e += WROWS) {
-      const int b = (int)(e >> kC), nb = bits[16 + b];
-      const uint32_t Tc = e & ((1u << kC) - 1u);
-      T r = thc[nb * k + nb];
-      for (int i = 0; i < kC; ++i) if (i != b && ((Tc >> i) & 1u)) r *= thc[nb * k + bits[16 + i]];
-      Rc[b * RCS + rcidx(Tc)] = r;
-    }
-    for (uint32_t e = tid; e < (1u << kC); e += WROWS) dCt[rcidx(e)] = dCg[e];
-    for (int e = tid; e < kR * 64; e += WROWS) {
-      const int i = e >> 6, l = e & 63, nb = bits[i];
-      T r = T(1);
-      for (int j = 0; j < WLB; ++j) if (j != i && ((l >> j) & 1)) r *= thc[nb * k + bits[j]];
-      Lr[e] = r;
-    }
-    for (int e = tid; e < kR * 16; e += WROWS) {
-      const int i = e >> 4, u = e & 15, nb = bits[i];
-      T r = thc[nb * k + nb];
-      for (int j = 0; j < WWB; ++j) if (WLB + j != i && ((u >> j) & 1)) r *= thc[nb * k + bits[WLB + j]];
-      Ur[e] = r;
-    }
-    for (int e = tid; e < kR * 32; e += WROWS) {
-      const int i = e >> 5, u = e & 31, nb = bits[i];
-      T r = T(1);
-      for (int j = 0; j < nXr; ++j) if (WTB + j != i && ((u >> j) & 1)) r *= thc[nb * k + bits[WTB + j]];
-      Er[e] = r;
-    }
-    // ---- seed = 0 part: lattice over the paired events (only PT == MT states carry values)
-    auto solve_eq = [&]() {
+    const long long ybase = sgpr64(d0.off);                    // patient j of the chain: y + ybase + (j << k)
+    const uint32_t NXS = 1u << nX, mXc = (1u << nXc) - 1u;
+    const uint32_t Sxfull = (1u << nXr) - 1u, Txfull = mXc;
+    const uint32_t PATB = (uint32_t)(sizeof(T) << k), HALFB = PATB >> 1;   // bytes of a patient's vector / of its seeded half
+    const int NPASS = npat * (int)NXS + WLB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sgpr64((long long)reinterpret_cast<char*>(y + ybase))), 0,
+                                                        (int)sgpr((uint32_t)npat * PATB), 0x00020000);
+    // ---- a patient enters: its tables (buffer j & 1), forward: its seed = 0 lattice (only PT == MT states carry values).
+    // Every wave is at the same point here (deskew); the ring is dead.
+    auto solve_eq = [&](const WDesc& wd, const Desc& d, T* se) {
+      const long long base = d.off;
+      const T* dP = tab + d.toff + rate_table_size(k);
+      const T* dE = dP + (1ll << __popc(d.maskP)) + (1ll << __popc(d.maskM));
+      const T* ym = y + base + half;
       const uint32_t pairP = sgpr(d.pairP);
       const int ke = __popc(pairP);
-      const T* dE = dM + (1ll << __popc(sgpr(d.maskM)));
       const uint32_t VE = 1u << ke;
       const T seed_base = thc[seedb * k + seedb];
       for (int s = 0; s <= ke; ++s) {
@@ -256,16 +247,77 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         __syncthreads();
       }
     };
-    if (!TR) solve_eq();
-    __syncthreads();                                           // tables complete; thc (ring area) is free from here on
-    // ---- per-lane constants of the patient
-    const JLink<T>* Lk = links + prob;
-    const int rowpart = majP ? 0 : 1, colpart = 1 - rowpart;
-    const uint32_t NXS = 1u << nX, mXc = (1u << nXc) - 1u;
-    const int NSIG = (int)NXS + WLB;
-    const uint32_t Sxfull = (1u << nXr) - 1u, Txfull = mXc;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sgpr64((long long)reinterpret_cast<char*>(ym))), 0,
-                                                        (int)sgpr((uint32_t)((unsigned long long)half * sizeof(T))), 0x00020000);
+    auto load_thc = [&](const Desc& d) {
+      const T* src = tab + d.toff;
+      for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
+    };
+    auto enter = [&](int j) {
+      const WDesc& wd = wds[first + j];
+      const Desc& d = descs[wd.prob];
+      T* const tb = lds + L::tab0 + (j & 1) * L::TABSZ;
+      const bool majP = wd.majP != 0;
+      const T* dP = tab + d.toff + rate_table_size(k);
+      const T* dM = dP + (1ll << __popc(d.maskP));
+      const T* dCg = majP ? dM : dP;
+      __syncthreads();                                         // every wave has left the steps before: ring and buffer j & 1 are free
+      load_thc(d);
+      __syncthreads();
+      // rates of the column-class events from the column sets without the event
+      for (uint32_t e = tid; e < ((uint32_t)kC << (kC - 1)); e += WROWS) {
+        const int b = (int)(e >> (kC - 1)), nb = wd.cb[b];
+        const uint32_t u = e & ((1u << (kC - 1)) - 1u);
+        const uint32_t Tc = ((u >> b) << (b + 1)) | (u & ((1u << b) - 1u));      // the column set (bit b clear)
+        T r = thc[nb * k + nb];
+        for (int i = 0; i < kC; ++i) if ((Tc >> i) & 1u) r *= thc[nb * k + wd.cb[i]];
+        uint32_t idx;
+        if (b < WB) idx = b * SZLO + (Tc >> WB) * LOS + squeeze(Tc & (uint32_t)(WIN - 1), b);
+        else idx = WB * SZLO + (b - WB) * SZHI + squeeze(Tc >> WB, b - WB) * HIS + (Tc & (uint32_t)(WIN - 1));
+        tb[L::oRh + idx] = r;
+      }
+      for (uint32_t e = tid; e < (1u << kC); e += WROWS) tb[L::oDC + (e >> WB) * HIS + (e & (uint32_t)(WIN - 1))] = dCg[e];
+      for (int e = tid; e < kR * 64; e += WROWS) {
+        const int i = e >> 6, l = e & 63, nb = wd.rb[i];
+        T r = T(1);
+        for (int q = 0; q < WLB; ++q) if (q != i && ((l >> q) & 1)) r *= thc[nb * k + wd.rb[q]];
+        tb[L::oLr + e] = r;
+      }
+      for (int e = tid; e < kR * 16; e += WROWS) {
+        const int i = e >> 4, u = e & 15, nb = wd.rb[i];
+        T r = thc[nb * k + nb];
+        for (int q = 0; q < WWB; ++q) if (WLB + q != i && ((u >> q) & 1)) r *= thc[nb * k + wd.rb[WLB + q]];
+        tb[L::oUr + e] = r;
+      }
+      for (int e = tid; e < kR * 32; e += WROWS) {
+        const int i = e >> 5, u = e & 31, nb = wd.rb[i];
+        T r = T(1);
+        for (int q = 0; q < nXr; ++q) if (WTB + q != i && ((u >> q) & 1)) r *= thc[nb * k + wd.rb[WTB + q]];
+        tb[L::oEr + e] = r;
+      }
+      if (tid == 0) {
+        WPInfo<T>& pi_ = pinfo[j & 1];
+        pi_.droff = d.toff + rate_table_size(k) + (majP ? 0 : (1ll << __popc(d.maskP)));
+        const JLink<T>& Lk = links[wd.prob];
+        const int rowpart = majP ? 0 : 1;
+        for (int q = 0; q < 2; ++q) {
+          const int part = q == 0 ? rowpart : 1 - rowpart;
+          pi_.soff[q] = (TR && Lk.soff[part] >= 0) ? Lk.soff[part] + (1ll << (Lk.sk[part] - 1)) : -1;
+          pi_.cst[q] = TR ? Lk.cst[part] : T(0);
+        }
+        pi_.pairRowC = wd.pairRowC; pi_.loneRowC = wd.loneRowC;
+        for (int i = 0; i < 16; ++i) pi_.prt[i] = wd.prt[i] < 0 ? 0 : wd.prt[i];
+      }
+      if (!TR) solve_eq(wd, d, tb + L::oSe);
+      __syncthreads();
+    };
+    auto leave = [&](int j) {                                  // transposed: the seed = 0 lattice of a patient whose seeded half is complete
+      const WDesc& wd = wds[first + j];
+      const Desc& d = descs[wd.prob];
+      __syncthreads();                                         // (waits for the stores of every wave as well)
+      load_thc(d);
+      __syncthreads();
+      solve_eq(wd, d, nullptr);
+      __syncthreads();
+    };
     auto ld_row = [&](uint32_t off, uint32_t soff) -> VecT {
       Raw r;
       r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)soff, 0);
@@ -288,43 +340,43 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     for (int b = 0; b < H; ++b)
 #pragma unroll
       for (int c = 0; c < NC; ++c) Wd[b][c] = T(0);
-    // ---- state of the current window pass (per lane: the lanes of a wave differ in their external index)
-    // Sigma: external index (0 on a lane that is outside the pipeline), soff: byte offset of its blocks (beyond the
-    // buffer on such a lane: its stores are dropped, its loads return zeros), rcb: offset of its column tables
-    uint32_t Sigma = 0, rcb = 0, goff = 0, soff = OOB;
-    int cur_sig = 0;
+    // ---- state of the current window pass (per lane: the lanes of a wave differ in their patient and external index)
+    // Sigma: external index (0 on a lane that is outside the pipeline), soff: byte offset of its blocks inside the chain
+    // (beyond the buffer on such a lane: its stores are dropped, its loads return zeros), tbo: its patient's tables
+    uint32_t Sigma = 0, soff = OOB, tbo = L::tab0;
     T cL[WLB], dRv = T(1);
     uint32_t hitT = 0xffffffffu, hitE = 0;
-    // (thread-derived values are re-derived from an opaque copy of the thread id inside every step / pass: hipcc would
-    // otherwise hoist a dozen loop-invariant LDS addresses out of the step loop and spill them)
-    auto opaque_tid = [&]() -> uint32_t { uint32_t t = (uint32_t)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
-      const int Sg = sig - (TR ? WLB - __popc(ln) : __popc(ln));
-      cur_sig = sig;
-      const bool act = (unsigned)Sg < NXS;
-      Sigma = act ? (TR ? NXS - 1u - (uint32_t)Sg : (uint32_t)Sg) : 0u;
+      const int V = sig - (TR ? WLB - __popc(ln) : __popc(ln));
+      const bool act = (unsigned)V < (unsigned)npat * NXS;
+      const uint32_t Vc = act ? (uint32_t)V : 0u;
+      const uint32_t j = Vc >> nX, g = Vc & (NXS - 1u);
+      Sigma = TR ? NXS - 1u - g : g;
       const uint32_t Sx = Sigma >> nXc;
-      rcb = (Sigma & mXc) * (uint32_t)(WIN + PAD);
-      goff = (Sigma << BSH) + voff;
-      soff = act ? goff : OOB;
+      tbo = L::tab0 + (j & 1u) * L::TABSZ;
+      soff = act ? j * PATB + HALFB + (Sigma << BSH) + wrho(tt >> 6, ln) * (uint32_t)sizeof(VecT) : OOB;
+      const T* tb = lds + tbo;
+      const WPInfo<T>& pi_ = pinfo[j & 1u];
 #pragma unroll
       for (int i = 0; i < WLB; ++i) {
         const bool has = TR ? !((ln >> i) & 1u) : ((ln >> i) & 1u);
-        const T r = Lr[i * 64 + ln] * Ur[i * 16 + wv] * Er[i * 32 + Sx];
+        const T r = tb[L::oLr + i * 64 + ln] * tb[L::oUr + i * 16 + wv] * tb[L::oEr + i * 32 + Sx];
         cL[i] = has ? r : T(0);
       }
-      dRv = dRg[tt | (Sx << WTB)];
+      dRv = tab[pi_.droff + (tt | (Sx << WTB))];
       if (!TR) {
         // forward right-hand side: seeding enters row S at the one column whose paired events are those of S
         const uint32_t S = tt | (Sx << WTB);
-        uint32_t hT = 0, e = 0, ebit = 1u;
-        for (uint32_t pm = sgpr(wd.pairRowC); pm; pm &= pm - 1) {          // (scalar loop: at most MKE pairs)
-          const int i = __ffs(pm) - 1;
-          if ((S >> i) & 1u) { hT |= 1u << bits[32 + i]; e |= ebit; }
-          ebit <<= 1;
+        const uint32_t pairRowC = pi_.pairRowC;
+        uint32_t hT = 0, e = 0, ne = 0;
+        for (int i = 0; i < kR; ++i) {
+          const uint32_t isp = (pairRowC >> i) & 1u, on = isp & (S >> i);
+          hT |= on << pi_.prt[i];
+          e |= on << ne;
+          ne += isp;
         }
-        hitT = (S & sgpr(wd.loneRowC)) ? 0xffffffffu : hT;
+        hitT = (S & pi_.loneRowC) ? 0xffffffffu : hT;
         hitE = e;
       }
     };
@@ -334,25 +386,33 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       constexpr int beta = TR ? H - 1 - BI : BI;
       constexpr uint32_t boff = (uint32_t)beta * BLKB;
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
+      // (derived afresh in every step from opaque copies: common subexpressions of the eight steps of a pass would be
+      // kept in registers over the whole pass and spilled)
+      uint32_t Sgo = Sigma, tbx = tbo;
+      asm volatile("" : "+v"(Sgo), "+v"(tbx));
+      const T* tb = lds + tbx;
+      const uint32_t Tx = Sgo & mXc, Sx = Sgo >> nXc;
       T acc[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = T(0);
       // external moves: the thread's own earlier blocks.  A move that does not exist is requested beyond the end of
       // the buffer (zeros come back, nothing is touched): no per-move control flow.
       auto ext_off = [&](int j) -> uint32_t {
-        const bool has = TR ? !((Sigma >> j) & 1u) : ((Sigma >> j) & 1u);
-        return (has && soff != OOB) ? (goff ^ (1u << (j + BSH))) : OOB;
+#ifdef MMHN_WABL_NOLOAD   // timing-only ablation (wrong results): no external block is read
+        return OOB;
+#endif
+        const bool has = TR ? !((Sgo >> j) & 1u) : ((Sgo >> j) & 1u);
+        return (has && soff != OOB) ? (soff ^ (1u << (j + BSH))) : OOB;
       };
       auto ext_take = [&](int j, const VecT& nv) {
         if (j < nXc) {
-          // column move: rate of column bit WB + j from the source column set
-          const uint32_t Tx = Sigma & mXc;
-          const uint32_t srcTx = TR ? Tx : (Tx & ~(1u << j));
-          const VecT rr = lds_vec(Rc + (WB + j) * RCS + srcTx * (uint32_t)(WIN + PAD) + beta * NC);
+          // column move: rate of column bit WB + j from the source column set (bit j of Tx clear there)
+          const VecT rr = lds_vec(tb + L::oRh + WB * SZLO + j * SZHI + squeeze(Tx, j) * HIS + beta * NC);
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], nv[c], acc[c]);
         } else {
-          const T r = Lr[(WTB + (j - nXc)) * 64 + ln] * Ur[(WTB + (j - nXc)) * 16 + wv] * Er[(WTB + (j - nXc)) * 32 + (Sigma >> nXc)];
+          const int i = WTB + (j - nXc);
+          const T r = tb[L::oLr + i * 64 + ln] * tb[L::oUr + i * 16 + wv] * tb[L::oEr + i * 32 + Sx];
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] = fma_m(r, nv[c], acc[c]);
         }
@@ -361,7 +421,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       if (nX > 0) ev0 = ld_row(ext_off(0), boff);
       if (nX > 1) ev1 = ld_row(ext_off(1), boff);
       __builtin_amdgcn_sched_barrier(0);
-      // lane moves: the neighbour lane's window slot (its previous window pass = this lane's external index)
+      // lane moves: the neighbour lane's window slot (its previous window pass = this lane's pass)
       {
         const VecT old = Wd[beta];
 #pragma unroll
@@ -375,6 +435,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(0);
       if (nX > 0) ext_take(0, ev0);
       if (nX > 1) ext_take(1, ev1);
       if (nX > 2) {
@@ -382,6 +443,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         if (nX > 3) ev1 = ld_row(ext_off(3), boff);
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(1);
       // wave moves: the block the neighbour wave published one step ago
       {
         const T* rs = ring + (uint32_t)(gpar ^ 1) * (NC * WROWS);
@@ -394,20 +456,24 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
             r.q[0] = *reinterpret_cast<const u32x4*>(rs + row * QE);
             r.q[1] = *reinterpret_cast<const u32x4*>(rs + WROWS * QE + row * QE);
             const VecT nv = __builtin_bit_cast(VecT, r);
-            const T cw = Lr[(WLB + j) * 64 + ln] * Ur[(WLB + j) * 16 + wv] * Er[(WLB + j) * 32 + (Sigma >> nXc)];
+            const T cw = tb[L::oLr + (WLB + j) * 64 + ln] * tb[L::oUr + (WLB + j) * 16 + wv] * tb[L::oEr + (WLB + j) * 32 + Sx];
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = fma_m(cw, nv[c], acc[c]);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(2);
       // window moves: own blocks of this window pass
 #pragma unroll
       for (int j = 0; j < HB; ++j) {
         const bool has = TR ? !((beta >> j) & 1) : ((beta >> j) & 1);
         if (has) {                                             // compile-time
+          constexpr int dummy = 0; (void)dummy;
           const int sb = beta ^ (1 << j);
-          const VecT rr = lds_vec(Rc + (RB + j) * RCS + rcb + (TR ? beta : sb) * NC);
+          const int wset = ((TR ? beta : sb) << RB);           // the window setting the rate is taken at (bit RB + j clear)
+          const int wsq = ((wset >> (RB + j + 1)) << (RB + j)) | (wset & ((1 << (RB + j)) - 1));
+          const VecT rr = lds_vec(tb + L::oRh + (RB + j) * SZLO + Tx * LOS + wsq);
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], Wd[sb][c], acc[c]);
         }
@@ -423,32 +489,33 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(3);
       // right-hand side
-      const uint32_t Tblk = ((Sigma & mXc) << HB) | (uint32_t)beta;       // column set of the block >> RB
+      const uint32_t Tblk = (Tx << HB) | (uint32_t)beta;       // column set of the block >> RB
       if (!TR) {
         if (__builtin_amdgcn_ballot_w64((hitT >> RB) == Tblk) != 0ull) {  // (rare: skipped by a scalar branch)
-          const T hv = (hitT >> RB) == Tblk ? se[hitE] : T(0);
+          const T hv = (hitT >> RB) == Tblk ? tb[L::oSe + hitE] : T(0);
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] += ((hitT & (uint32_t)(NC - 1)) == (uint32_t)c) ? hv : T(0);
         }
       } else {
-        if (wv == WROWS / 64 - 1) {                                       // the last row of the last external row setting
-          if (ln == 63u && (Sigma >> nXc) == Sxfull && soff != OOB && Lk->soff[rowpart] >= 0) {
-            const T* qr = qS + Lk->soff[rowpart] + (1ll << (Lk->sk[rowpart] - 1)) + ((long long)Tblk << RB);
-            const T cr = Lk->cst[rowpart];
+        const WPInfo<T>& pi_ = pinfo[tbx != (uint32_t)L::tab0];
+        if (wv == WROWS / 64 - 1) {                            // the last row of the last external row setting
+          if (ln == 63u && Sx == Sxfull && soff != OOB && pi_.soff[0] >= 0) {
+            const T* qr = qS + pi_.soff[0] + ((long long)Tblk << RB);
+            const T cr = pi_.cst[0];
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] += cr * qr[c];
           }
         }
-        if (beta == H - 1) {                                              // the last column
-          if ((Sigma & mXc) == Txfull && soff != OOB && Lk->soff[colpart] >= 0)
-            acc[NC - 1] += Lk->cst[colpart] * qS[Lk->soff[colpart] + (1ll << (Lk->sk[colpart] - 1)) + (tt | ((Sigma >> nXc) << WTB))];
+        if (beta == H - 1) {                                   // the last column
+          if (Tx == Txfull && soff != OOB && pi_.soff[1] >= 0)
+            acc[NC - 1] += pi_.cst[1] * qS[pi_.soff[1] + (tt | (Sx << WTB))];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       // the block itself: moves along the RB lowest column bits (only the rates in use are fetched), diagonal
-      const T* rcp_ = Rc + rcb + beta * NC;
-      const VecT dcv = lds_vec(dCt + rcb + beta * NC);
+      const VecT dcv = lds_vec(tb + L::oDC + Tx * HIS + beta * NC);
       VecT Y;
       if (!TR) {
 #pragma unroll
@@ -456,7 +523,12 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           T z = acc[c];
 #pragma unroll
           for (int r = 0; r < RB; ++r)
-            if ((c >> r) & 1) z = fma_m(rcp_[r * RCS + (c ^ (1 << r))], Y[c ^ (1 << r)], z);
+            if ((c >> r) & 1) {
+              constexpr int dummy = 0; (void)dummy;
+              const int wset = (beta << RB) | (c ^ (1 << r));
+              const int wsq = ((wset >> (r + 1)) << r) | (wset & ((1 << r) - 1));
+              z = fma_m(tb[L::oRh + r * SZLO + Tx * LOS + wsq], Y[c ^ (1 << r)], z);
+            }
           Y[c] = z * fast_rcp(dRv + dcv[c]);
         }
       } else {
@@ -465,67 +537,62 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           T z = acc[c];
 #pragma unroll
           for (int r = 0; r < RB; ++r)
-            if (!((c >> r) & 1)) z = fma_m(rcp_[r * RCS + c], Y[c | (1 << r)], z);
+            if (!((c >> r) & 1)) {
+              const int wset = (beta << RB) | c;
+              const int wsq = ((wset >> (r + 1)) << r) | (wset & ((1 << r) - 1));
+              z = fma_m(tb[L::oRh + r * SZLO + Tx * LOS + wsq], Y[c | (1 << r)], z);
+            }
           Y[c] = z * fast_rcp(dRv + dcv[c]);
         }
       }
       Wd[beta] = Y;
-#ifdef MMHN_W_PREFETCH       // (measured: +2.5 / +6 ms per solve - the memory system is bound by its request rate)
-      // the external blocks of the NEXT step: one dword of each row is requested now and lands in a junk area of LDS (no
-      // register, nothing waits for it) - it pulls the lines into L2 a step ahead, the step's own loads then find them there
-      {
-        uint32_t g2 = goff, S2 = Sigma;
-        bool a2 = soff != OOB;
-        constexpr uint32_t boff2 = (uint32_t)(TR ? (BI + 1 < H ? beta - 1 : H - 1) : (BI + 1 < H ? beta + 1 : 0)) * BLKB;
-        if constexpr (BI + 1 == H) {                           // first block of the next window pass
-          const int Sg2 = cur_sig + 1 - (TR ? WLB - __popc(ln) : __popc(ln));
-          a2 = (unsigned)Sg2 < NXS;
-          S2 = a2 ? (TR ? NXS - 1u - (uint32_t)Sg2 : (uint32_t)Sg2) : 0u;
-          g2 = (S2 << BSH) + voff;
-        }
-        for (int j = 0; j < nX; ++j) {
-          const bool has = TR ? !((S2 >> j) & 1u) : ((S2 >> j) & 1u);
-          const uint32_t o2 = (has && a2) ? (g2 ^ (1u << (j + BSH))) : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, junk, 4, (int)o2, (int)boff2, 0, 0);
-        }
-      }
-#endif
       if (TR ? wv != 0 : wv != WROWS / 64 - 1) {               // some wave above / below reads it
         T* ws = ring + (uint32_t)gpar * (NC * WROWS);
         const Raw r = __builtin_bit_cast(Raw, Y);
         *reinterpret_cast<u32x4*>(ws + tt * QE) = r.q[0];
         *reinterpret_cast<u32x4*>(ws + WROWS * QE + tt * QE) = r.q[1];
       }
+#ifdef MMHN_WABL_NOSTORE  // timing-only ablation (wrong results): nothing is written
+      st_row(OOB, boff, Y);
+#else
       st_row(soff, boff, Y);
+#endif
+      STAMP(4);
     };
-    // ---- the pipeline: wave-level lam delays the wave by lam steps, lane-level m delays a lane by m window passes
-    for (int s = 0; s < lam; ++s) lds_barrier();
-    for (int sig = 0; sig < NSIG; ++sig) {
+    // ---- the pipeline: wave-level lam delays the wave by lam steps, lane-level m delays a lane by m window passes;
+    // a patient enters every 2^nX passes (the waves meet for its tables: four steps of slack) and, transposed, is
+    // completed by its seed = 0 lattice six passes after the next one entered
+    enter(0);
+    reskew();
+    for (int sig = 0; sig < NPASS; ++sig) {
+      const uint32_t ph = (uint32_t)sig & (NXS - 1u);
+      const int jj = sig >> nX;
+      if (ph == 0 && jj >= 1 && jj < npat) { deskew(); enter(jj); reskew(); }
+      if (TR && ph == (uint32_t)WLB && jj >= 1) { deskew(); leave(jj - 1); reskew(); }
+ STAMP(7);
       begin_pass(sig);
+      STAMP(6);
       const int g0 = lam & 1;                                  // parity of the global step (H is even)
-      step(IC<0>{}, g0); lds_barrier();
-      step(IC<1>{}, g0 ^ 1); lds_barrier();
+      step(IC<0>{}, g0); lds_barrier(); STAMP(5);
+      step(IC<1>{}, g0 ^ 1); lds_barrier(); STAMP(5);
       if constexpr (H > 2) {
-        step(IC<2 % H>{}, g0); lds_barrier();
-        step(IC<3 % H>{}, g0 ^ 1); lds_barrier();
+        step(IC<2 % H>{}, g0); lds_barrier(); STAMP(5);
+        step(IC<3 % H>{}, g0 ^ 1); lds_barrier(); STAMP(5);
       }
       if constexpr (H > 4) {
-        step(IC<4 % H>{}, g0); lds_barrier();
-        step(IC<5 % H>{}, g0 ^ 1); lds_barrier();
-        step(IC<6 % H>{}, g0); lds_barrier();
-        step(IC<7 % H>{}, g0 ^ 1); lds_barrier();
+        step(IC<4 % H>{}, g0); lds_barrier(); STAMP(5);
+        step(IC<5 % H>{}, g0 ^ 1); lds_barrier(); STAMP(5);
+        step(IC<6 % H>{}, g0); lds_barrier(); STAMP(5);
+        step(IC<7 % H>{}, g0 ^ 1); lds_barrier(); STAMP(5);
       }
       static_assert(H == 2 || H == 4 || H == 8, "window of 2, 4 or 8 blocks");
     }
-    for (int s = lam; s < WWB; ++s) lds_barrier();
-    if (TR) {
-      __syncthreads();                                         // every store of the seeded half has landed; the ring is free
-      const T* src = tab + toff;
-      for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
-      __syncthreads();
-      solve_eq();
-    }
+    deskew();
+    if (TR) leave(npat - 1);
+    __syncthreads();
+    STAMP(7);
   }
+  STAMP_FLUSH(TR ? 8 : 0);
 }
 
 // window layout -> natural index order (seeded half; the PT == MT states of the seed = 0 half are copied)
