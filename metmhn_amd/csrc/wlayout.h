@@ -49,7 +49,7 @@ constexpr int WNXR = WKR - WTB;
 template <typename T> struct WCfg;
 // RB: column bits of a block, HB: blocks of a window, KC: most column-class bits (their rate table lives in LDS),
 // PAD: elements between the table rows of two external column settings (16 bytes: the lanes of a wave differ in it)
-template <> struct WCfg<double> { static constexpr int RB = 2, HB = 3, KC = 9, PAD = 2; };
+template <> struct WCfg<double> { static constexpr int RB = 2, HB = 2, KC = 9, PAD = 2; };
 template <> struct WCfg<float> { static constexpr int RB = 3, HB = 3, KC = 10, PAD = 4; };
 
 // static description of one joint problem on the window path (host-built, set_cohort)
