@@ -125,6 +125,11 @@ struct Batch {
   DevArr<WDesc> d_wd;
   std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
   DevArr<WChain> d_wchains;
+  // the few problems the window path leaves over: tile-level solver (one patient walking its tiles alone takes ~2 ms)
+  std::vector<int2> lmapO;
+  std::vector<int> lofO;
+  DevArr<int2> d_lmapO;
+  int maxkO = 0;
   bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
   int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
   std::vector<int> ptoff;
@@ -729,6 +734,14 @@ struct Engine : EngineBase {
       nold = (int)b.olist.size();
       plist = b.d_olist.p;
       if (nold == 0) return;
+      if (!b.lmapO.empty()) {
+        // a handful of left-over problems: tile by tile, level by level (parallel over their tiles); the solver skips dead
+        // tiles, which its consumers read: cleared first
+        for (int pj : b.olist) zero(y + b.dJ[pj].off, 1ll << b.dJ[pj].k);
+        const PList LO{b.d_dJ.p, nullptr, (int)b.lmapO.size(), b.maxkO, 0, b.d_lmapO.p, &b.lofO, tabJ.p};
+        solve(tr, LO, y, nullptr, nullptr, rhs_mode, nullptr);
+        return;
+      }
     }
     if (b.mpath) {
       // matrix path: the solution is written once (seeded half)
@@ -1014,6 +1027,15 @@ struct Engine : EngineBase {
         up(b.d_wd, b.wd);
         up(b.d_olist, b.olist);
         up(b.d_wchains, b.wchains);
+        b.lmapO.clear(); b.lofO.clear(); b.maxkO = 0;
+        if (!b.olist.empty() && b.olist.size() <= 64) {
+          std::vector<char> left(b.dJ.size(), 0);
+          for (int pj : b.olist) { left[pj] = 1; b.maxkO = std::max(b.maxkO, b.dJ[pj].k); }
+          std::vector<int2> mo;
+          for (const int2& m : b.mapJ) if (left[m.x]) mo.push_back(m);
+          build_levels(mo, &b.dJ, true, b.lmapO, b.lofO);
+          up(b.d_lmapO, b.lmapO);
+        }
       }
       b.mapX.clear();
       for (const int2& m : b.mapJ) {
