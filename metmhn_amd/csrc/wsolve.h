@@ -346,6 +346,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     uint32_t Sigma = 0, soff = OOB, tbo = L::tab0;
     T cL[WLB], dRv = T(1);
     uint32_t hitT = 0xffffffffu, hitE = 0;
+    uint32_t rowkey = 0xffffffffu;                             // (patient, external row setting) the row constants were formed for
+    const uint32_t voff = wrho((uint32_t)tid >> 6, (uint32_t)tid & 63u) * (uint32_t)sizeof(VecT);
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
       const int V = sig - (TR ? WLB - __popc(ln) : __popc(ln));
@@ -355,7 +357,12 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       Sigma = TR ? NXS - 1u - g : g;
       const uint32_t Sx = Sigma >> nXc;
       tbo = L::tab0 + (j & 1u) * L::TABSZ;
-      soff = act ? j * PATB + HALFB + (Sigma << BSH) + wrho(tt >> 6, ln) * (uint32_t)sizeof(VecT) : OOB;
+      soff = act ? j * PATB + HALFB + (Sigma << BSH) + voff : OOB;
+      // the rates along the lane bits, the row part of the diagonal and the seeding column depend on the row alone:
+      // formed again only in a pass in which some lane of the wave moves to another patient or external row setting
+      const uint32_t key = (j << 8) | Sx;
+      if (__builtin_amdgcn_ballot_w64(key != rowkey) == 0ull) return;
+      rowkey = key;
       const T* tb = lds + tbo;
       const WPInfo<T>& pi_ = pinfo[j & 1u];
 #pragma unroll
