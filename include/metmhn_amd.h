@@ -193,6 +193,11 @@ typedef struct {
   double eval_ms;    /* host wall time spent inside evaluations */
   int64_t evals;
 } mmhn_counters;
+/* ABI version of this header: bumped whenever an exported signature changes (4: mmhn_bench_kronvec has its `tiles`
+ * argument, mmhn_debug_lane_moves exists).  A client built against another header must refuse to run:
+ * mmhn_abi_version() != MMHN_ABI_VERSION (metmhn_amd/_lib.py checks it on load). */
+#define MMHN_ABI_VERSION 4
+int mmhn_abi_version(void);
 int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch,
                        int iters, int transpose, int jacobi, double* ms_per_launch, int64_t* tiles);
 /* device-memory bandwidth of this GPU for a plain 16-byte-per-lane stream over arrays of `bytes` each

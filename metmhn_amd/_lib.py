@@ -73,7 +73,8 @@ SIGNATURES = {
     "mmhn_reset_counters": [C.c_void_p],
     "mmhn_debug_lane_moves": [C.c_void_p, C.c_int, C.POINTER(C.c_int)],
 }
-OTHER_SYMBOLS = ("mmhn_destroy", "mmhn_last_error")
+OTHER_SYMBOLS = ("mmhn_destroy", "mmhn_last_error", "mmhn_abi_version")
+ABI_VERSION = 4          # MMHN_ABI_VERSION of include/metmhn_amd.h these prototypes were written against
 
 
 def needs_build() -> bool:
@@ -129,6 +130,11 @@ def load():
     lib.mmhn_destroy.restype = None
     lib.mmhn_last_error.argtypes = []
     lib.mmhn_last_error.restype = C.c_char_p
+    lib.mmhn_abi_version.argtypes = []
+    lib.mmhn_abi_version.restype = C.c_int
+    if lib.mmhn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.mmhn_abi_version()}, these bindings expect {ABI_VERSION} - rebuild "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

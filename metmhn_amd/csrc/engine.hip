@@ -1211,6 +1211,9 @@ struct Engine : EngineBase {
     REQUIRE(!sums_pending, "an evaluation begun with mmhn_cohort_sums_begin has not been collected");
     auto t0 = std::chrono::steady_clock::now();
     const int st = stride();
+    // (an evaluation that threw between a fork and its join must not leave its flags to the next one: the side stream
+    // would wait for the previous evaluation's event and start before this one's parameters are up)
+    small_forked[0] = small_forked[1] = fork_recorded[0] = fork_recorded[1] = false;
     // the head of the evaluation: parameters up, cohort sums and the first batch's gradient work arrays cleared
     bool head_done = false;
     if (zero_copy && !batches.empty()) {
@@ -1919,7 +1922,7 @@ int mmhn_cohort_wsums_begin(mmhn_handle h, const double* lt, const double* ldp, 
   API_BEGIN
   GUARD(h);
   REQUIRE(lt && ldp && ldm, "null pointer");
-  REQUIRE(w == w, "w must be a number");
+  REQUIRE(std::isfinite(w), "w must be finite");
   DISPATCH(h, cohort_sums_begin(lt, ldp, ldm, with_grad != 0, &w));
   API_END
 }
@@ -2305,6 +2308,8 @@ int mmhn_debug_lane_moves(mmhn_handle h, int transposed, int* out) {
   HIPCHECK(hipStreamSynchronize(h->impl->stream));
   API_END
 }
+
+int mmhn_abi_version(void) { return MMHN_ABI_VERSION; }
 
 int mmhn_reset_counters(mmhn_handle h) {
   API_BEGIN

@@ -83,8 +83,11 @@ def allreduce_sums_fixed_order(sums: np.ndarray, group=None) -> np.ndarray:
 
 
 def em_weight(n_em: float, n_pat: float, perc_met: float):
-    """(w, n_full) of regularized_optimization.py:121-128 from the GLOBAL counts."""
+    """(w, n_full) of regularized_optimization.py:121-128 from the GLOBAL counts.  perc_met = 1 with both kinds of
+    rows present makes the reference's weight infinite (its score NaN): rejected here instead of reaching the device."""
     n_nm = n_pat - n_em
+    if n_em * n_nm != 0 and not (0.0 <= float(perc_met) < 1.0):
+        raise ValueError(f"perc_met must be in [0, 1) for a cohort with EM and NM rows, got {perc_met!r}")
     w = perc_met * n_nm / ((1 - perc_met) * n_em) if n_em * n_nm != 0 else 1.0
     return w, w * n_em + n_nm
 

@@ -20,13 +20,15 @@ from .engine import Engine
 
 _CACHE: dict = {}
 _MAX_CACHE = 4
-_OPTIONS = {"device": None, "dtype": "f64", "shard": True}
+_OPTIONS = {"device": None, "dtype": "f64", "shard": True, "strict_guard": False}
 
 
-def configure(device: int | None = None, dtype: str = "f64", shard: bool = True):
-    """Pick the GPU (default: LOCAL_RANK or 0), the engine dtype and whether to shard over ranks."""
+def configure(device: int | None = None, dtype: str = "f64", shard: bool = True, strict_guard: bool = False):
+    """Pick the GPU (default: LOCAL_RANK or 0), the engine dtype and whether to shard over ranks.
+    strict_guard: the cache guard hashes ALL of `dat` on every call (the reference is a pure function of `dat`);
+    default: all of it up to 256 KB, 64 sampled rows above that."""
     from .engine import set_default_device
-    _OPTIONS.update(device=device, dtype=dtype, shard=shard)
+    _OPTIONS.update(device=device, dtype=dtype, shard=shard, strict_guard=bool(strict_guard))
     set_default_device(device)
     invalidate()
 
@@ -123,11 +125,11 @@ _CRC_ROWS = {}
 
 
 def _sample_crc(dat: np.ndarray) -> int:
-    """Guard of the identity-keyed cache against in-place edits: CRC of up to 64 evenly spaced rows (a few KB, ~7 us
-    per call, run while the GPU evaluates - the reference is a pure function of `dat`, a full pass per evaluation
-    would cost more than a LUAD-sized evaluation itself).  Catches relabelled / masked / refilled cohorts; a single
+    """Guard of the identity-keyed cache against in-place edits, run while the GPU evaluates: the CRC of the whole array
+    up to 256 KB (every LUAD-sized cohort: ~50 us) or with configure(strict_guard=True); of 64 evenly spaced rows above
+    that (a full pass over a large cohort per evaluation would be host time on the critical path) - there a single
     edited row between the samples still needs invalidate()."""
-    if dat.shape[0] <= 64:
+    if dat.shape[0] <= 64 or dat.nbytes <= (256 << 10) or _OPTIONS["strict_guard"]:
         return zlib.crc32(np.ascontiguousarray(dat).tobytes())
     idx = _CRC_ROWS.get(dat.shape[0])
     if idx is None:
@@ -148,10 +150,11 @@ def _engine_for(dat, check: bool = True) -> Engine:
     key = _cache_key(dat, rank, world)
     hit = _CACHE.get(key)
     if hit is not None and (hit[1] is None or hit[1]() is dat):
-        if not check or not isinstance(dat, np.ndarray) or hit[0]._sample_crc == _sample_crc(dat):
+        if not check or not isinstance(dat, np.ndarray) or not _stale_anywhere(hit[0], dat, world):
             return hit[0]
-        _CACHE.pop(key)[0].close()                            # same array object, edited in place: lay it out again
-        hit = None
+        # same array object, edited in place: the SAME engine (callers may hold it; its communicator stays) gets the new rows
+        _load_rows(hit[0], dat, rank, world)
+        return hit[0]
     if hit is not None:                                       # the id was recycled for another array
         _CACHE.pop(key)[0].close()
     for k2 in [k2 for k2, (e2, r2) in _CACHE.items() if r2 is not None and r2() is None]:
@@ -161,12 +164,9 @@ def _engine_for(dat, check: bool = True) -> Engine:
         _CACHE.pop(next(iter(_CACHE)))[0].close()
     n_mut = (arr.shape[1] - 3) // 2
     eng = Engine(n_mut, device=_OPTIONS["device"], dtype=_OPTIONS["dtype"])
-    rows = arr if world == 1 else arr[_dist.shard_rows(arr, world)[rank]]
-    eng.set_cohort(rows)
-    # global EM / NM counts (every rank holds the whole `dat`): the weight of :121-128 is known without communication
-    eng._global_counts = (float(arr[:, -3].sum()), float(arr.shape[0]))
+    _load_rows(eng, dat, rank, world, arr)
     # MMHN_FORCE_ALLREDUCE=1: run the collective even with one rank (exercises the RCCL path on a 1-GPU box)
-    eng._sample_crc = _sample_crc(dat) if isinstance(dat, np.ndarray) else None
+    eng.world_size_hint = world
     eng._sharded = world > 1 or os.environ.get("MMHN_FORCE_ALLREDUCE") == "1"
     eng._device_comm = eng._sharded and _reduce_mode() != "host_fixed_order" and _join_comm(eng, rank, world)
     ref = None
@@ -177,6 +177,38 @@ def _engine_for(dat, check: bool = True) -> Engine:
             ref = None
     _CACHE[key] = (eng, ref)
     return eng
+
+
+def _load_rows(eng: Engine, dat, rank: int, world: int, arr=None):
+    """(Re)build the device layout of this rank's shard of `dat` on `eng`."""
+    if arr is None:
+        arr = np.ascontiguousarray(np.asarray(dat).astype(np.int8))
+    rows = arr if world == 1 else arr[_dist.shard_rows(arr, world)[rank]]
+    eng.set_cohort(rows)
+    # global EM / NM counts (every rank holds the whole `dat`): the weight of :121-128 is known without communication
+    eng._global_counts = (float(arr[:, -3].sum()), float(arr.shape[0]))
+    eng._sample_crc = _sample_crc(dat) if isinstance(dat, np.ndarray) else None
+
+
+def _stale_anywhere(eng: Engine, dat, world: int) -> bool:
+    """Has `dat` been edited in place since `eng` laid it out - on ANY rank (the ranks must decide together: a rebuild
+    and the repeated evaluation are collective)?"""
+    stale = isinstance(dat, np.ndarray) and eng._sample_crc != _sample_crc(dat)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([1 if stale else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        stale = bool(int(flag.item()))
+    return stale
+
+
+def _stale_anywhere_flag(stale: bool) -> bool:
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if stale else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(int(flag.item()))
 
 
 def _reduce_mode():
@@ -201,8 +233,12 @@ def _result(eng: Engine, log_theta, log_d_p, log_d_m, perc_met: float, with_grad
         aside = meanwhile() if meanwhile is not None and not stale else None
     finally:
         ws = eng.cohort_wsums_end()
+    if guard is not None and eng._sharded and eng.world_size_hint > 1:
+        stale = _stale_anywhere_flag(stale)
     if stale:
-        return _result(_engine_for(guard), log_theta, log_d_p, log_d_m, perc_met, with_grad, meanwhile)
+        rank, world = _rank_world() if _OPTIONS["shard"] else (0, 1)
+        _load_rows(eng, guard, rank, world)                   # the same engine (and communicator), the new rows
+        return _result(eng, log_theta, log_d_p, log_d_m, perc_met, with_grad, meanwhile)
     if eng._sharded and not eng._device_comm:
         ws = _dist.allreduce_sums_fixed_order(ws) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(ws)
     return _dist.split_wsums(ws, eng.N, n_full), aside

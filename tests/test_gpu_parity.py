@@ -246,7 +246,7 @@ def test_full_size_patients_against_optimised_cpu_variant(monkeypatch):
     from metmhn_amd import Engine, synthetic
     n = 20
     lt, dp, dm = synthetic.random_params(n)
-    dat = synthetic.full_k_cohort(n, 12, seed=2000 + n)
+    dat = synthetic.full_k_cohort(n, 64, seed=2000 + n)                      # (metmhn_fast.c: ~21 ms per patient and core)
     lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
     for pmin in ("1", "1000000"):
         monkeypatch.setenv("MMHN_PSOLVE_MIN", pmin)
@@ -1109,21 +1109,26 @@ def test_batched_kronvec_and_jacobi_step_fp32():
 @pytest.mark.gpu
 def test_small_space_path_fp32_on_luad_cohort(golden):
     """The small-space kernels (csrc/small.h: side-by-side marginal problems, in-kernel marginal right-hand sides) in
-    fp32 on the LUAD-reduced cohort, per patient against the fp64 engine at the fp32 bar: log-prob 1e-4 relative,
-    every gradient component within 2e-3 relative + 2e-5 absolute."""
+    fp32 on the LUAD-reduced cohort, per patient against the fp64 C port (oracle/metmhn_ref.c, cref.patients - itself
+    pinned to the reference on this cohort) at the fp32 bar: log-prob 1e-4 relative, every gradient component within
+    2e-3 relative + 2e-5 absolute; the fp64 engine on the same rows against the same port at 1e-9."""
+    from oracle import cref
     from metmhn_amd import Engine
     g = golden("luad_indep")
     dat, lt, dp, dm = g["dat"], g["indep_theta"], g["indep_dp"], g["indep_dm"]
     paired = np.flatnonzero(dat[:, -1] == 3)
     rows = np.concatenate((paired, np.arange(0, dat.shape[0], 23)))          # every paired row + a stride of the others
     sub = dat[rows]
+    ref = cref.patients(lt, dp, dm, sub)
     res = {}
     for dt in ("f64", "f32"):
         with Engine((dat.shape[1] - 3) // 2, dtype=dt) as e:
             e.set_cohort(sub)
             res[dt] = e.patient_grads(lt, dp, dm)
-    np.testing.assert_allclose(res["f32"][0], res["f64"][0], rtol=1e-4, atol=1e-5)
-    for nm, x32, x64 in zip(("d_theta", "d_dp", "d_dm"), res["f32"][1:], res["f64"][1:]):
+    for x, y in zip(res["f64"], ref):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res["f32"][0], ref[0], rtol=1e-4, atol=1e-5)
+    for nm, x32, x64 in zip(("d_theta", "d_dp", "d_dm"), res["f32"][1:], ref[1:]):
         err, tol = _fp32_report(f"LUAD {nm}", x32, x64)
         assert (err <= tol).all()
 
@@ -1242,3 +1247,94 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
             for x, y in zip(r1, res[2]):
                 assert np.isfinite(x).all()
                 np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+
+
+
+def _rccl_worker(rank, world, port, q):
+    """One rank of the in-library RCCL test: its own GPU, backend nccl, MMHN_STRICT_COMM=1 (no fallback to torch's
+    collective), the golden cohort c0 sharded over the ranks."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MMHN_STRICT_COMM"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import metmhn_amd.regularized_optimization as ro
+    ro.configure(device=rank)
+    g = np.load(os.path.join(root, "tests", "golden", "cohorts.npz"))
+    res = ro.score_and_grad(g["c0_log_theta"], g["c0_log_d_p"], g["c0_log_d_m"], g["c0_dat"], float(g["c0_perc_met"]))
+    eng = ro._engine_for(g["c0_dat"])
+    q.put((rank, eng.n_pat, bool(eng._device_comm), [np.asarray(r) for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_in_library_rccl_two_ranks(golden):
+    """The first multi-rank run of the in-library all-reduce (ncclCommInitRank with two ranks, one ncclAllReduce of the
+    pre-combined 1 + N^2 + 2N doubles per evaluation on each engine's stream): two processes, one GPU each, started before
+    anything touches a GPU here.  Needs two GPUs: skipped on a one-GPU box, runs by itself on any multi-GPU box.
+    Result of every rank == the unsharded reference result to 1e-12."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = golden("cohorts")
+    assert sorted(r[0] for r in got) == [0, 1]
+    assert all(r[2] for r in got), "the device communicator was not attached"
+    assert sum(r[1] for r in got) == g["c0_dat"].shape[0]
+    for _, _, _, res in got:
+        np.testing.assert_allclose(res[0], g["c0_score"], rtol=1e-12)
+        np.testing.assert_allclose(res[1], g["c0_d_th"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(res[2], g["c0_d_dp"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(res[3], g["c0_d_dm"], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_cache_guard_full_crc_and_in_place_refresh(golden):
+    """The cohort cache is keyed on the identity of `dat`; its guard hashes the whole array up to 256 KB (and always with
+    configure(strict_guard=True)): an in-place edit of ANY row is noticed, the SAME engine gets the new rows (a caller
+    holding it keeps a live handle), and the result equals a fresh evaluation of the edited cohort."""
+    import metmhn_amd.regularized_optimization as ro
+    from metmhn_amd import synthetic
+    n = 6
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.mixed_cohort(n, 300, seed=11)                            # 300 rows: beyond the 64 sampled rows
+    ro.configure()
+    s0 = ro.score(lt, dp, dm, dat, 0.3)
+    eng = ro._engine_for(dat)
+    sampled = set(np.linspace(0, dat.shape[0] - 1, 64).astype(int).tolist())
+    row = next(r for r in range(150, 300) if r not in sampled)               # not one of the 64 evenly spaced samples
+    old = dat[row].copy()
+    dat[row] = dat[(row + 7) % dat.shape[0]]
+    assert not np.array_equal(old, dat[row])
+    s1 = ro.score(lt, dp, dm, dat, 0.3)
+    assert ro._engine_for(dat) is eng and eng.h                              # same engine, still alive
+    ref = ro.score(lt, dp, dm, dat.copy(), 0.3)
+    np.testing.assert_allclose(s1, ref, rtol=1e-13)
+    assert abs(float(s1) - float(s0)) > 0
+    big = synthetic.mixed_cohort(n, 40000, seed=12)                          # 600 KB: sampled guard unless strict
+    ro.configure(strict_guard=True)
+    t0 = ro.score(lt, dp, dm, big, 0.3)
+    sampled = set(np.linspace(0, big.shape[0] - 1, 64).astype(int).tolist())
+    r2 = next(r for r in range(12345, 13000) if r not in sampled and not np.array_equal(big[r], big[54]))
+    big[r2] = big[54]
+    t1 = ro.score(lt, dp, dm, big, 0.3)
+    np.testing.assert_allclose(t1, ro.score(lt, dp, dm, big.copy(), 0.3), rtol=1e-13)
+    ro.configure()
