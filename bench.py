@@ -16,7 +16,7 @@ each), weak scaling; the cohort is resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line.  `value` counts 5 000-patient cohort evaluations per second
 over all ranks (N GPUs evaluate an N x 5 000 patient cohort per step).  `roofline` is the
-dominant kernel OF THE TIMED REGION (k_psolve, forward instantiation), timed with HIP events
+dominant kernel OF THE TIMED REGION (k_wsolve, forward instantiation), timed with HIP events
 on the engine's stream inside that region; every figure in the line can be recomputed from
 `alg_bytes_per_launch`, `avg_launch_ms` and the CSVs under profiles/.
 """
@@ -34,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_traffic.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r4_counters.json")
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector: half of the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md
 
 
 def csrc_sha16():
@@ -286,11 +288,17 @@ def main():
         tsrc = traffic.get("source", {})
         if tsrc.get("csrc_sha16") != csrc_sha16():      # PMC passes of another tree: not quoted
             traffic = {}
-        traffic_source = (f"recorded offline: profiles/r3_traffic.json (git {tsrc.get('git_head', '?')}, csrc {tsrc.get('csrc_sha16', '?')}; "
+        traffic_source = (f"recorded offline: profiles/r4_traffic.json (git {tsrc.get('git_head', '?')}, csrc {tsrc.get('csrc_sha16', '?')}; "
                           "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes over this same command; "
                           "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)")
         traffic_ok = a.workload == "full-k" and n == 20 and a.dtype == "f64" and a.patients == 5000 and bool(traffic)
         ek = traffic.get("eval_kernels", {}) if traffic_ok else {}
+        try:
+            counters = json.load(open(COUNTERS_FILE))
+        except Exception:
+            counters = {}
+        if counters.get("source", {}).get("csrc_sha16") != csrc_sha16() or not traffic_ok:
+            counters = {}
 
         # ---- measured stream bandwidth of this box (next to the nominal 8 TB/s)
         stream = {}
@@ -318,13 +326,33 @@ def main():
                 o["traffic_GBps"] = tr["bytes_per_launch"] / avg_ms / 1e6
             if stream:
                 o["frac_of_measured_copy"] = ach / stream["copy_GBps"]
+            # what bounds the kernel besides HBM (solves only): useful fp64 FMAs of the substitution = one per existing move
+            # of every seeded state + one for the diagonal = 2^K (K / 2 + 1) per patient (K = k - 1 index bits of the seeded
+            # half), against the fp64 vector peak; instruction counters from a separate PMC pass (profiles/r4_counters.json)
+            if name in ("psolve_fwd", "psolve_adj") and a.workload == "full-k":
+                K = n - 1
+                fmas = unit_rows * (2.0 ** K) * (K / 2.0 + 1.0)
+                o["useful_fp64_fma_per_launch"] = fmas
+                o["fp64_fma_TFLOPs"] = 2.0 * fmas / avg_ms / 1e9
+                o["fp64_fma_frac"] = o["fp64_fma_TFLOPs"] / FP64_VECTOR_PEAK_TFLOPS
+                ck = counters.get("kernels", {}).get(name)
+                if ck:
+                    states64 = unit_rows * (2.0 ** K) / 64.0
+                    o["valu_wave_insts_per_64_states"] = ck["SQ_INSTS_VALU"] / states64
+                    o["wave_insts_per_64_states"] = sum(ck.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                                                                                 "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) / states64
+                    o["waves_per_simd"] = ck.get("waves_per_simd")
+                    o["counters_source"] = f"recorded offline: profiles/r4_counters.json (git {counters['source'].get('git_head', '?')}), rocprofv3 --pmc SQ_INSTS_*"
             return o
 
         T = "double" if a.dtype == "f64" else "float"
-        rf_fwd = kern("psolve_fwd", f"k_psolve2<{T},false> (forward substitution solve, one workgroup per patient)",
-                      "solution written once: live (seeded) tiles x 2^12 x sizeof(dtype)")
-        rf_adj = kern("psolve_adj", f"k_psolve2<{T},true> (adjoint substitution solve)", "solution written once")
-        rf_marg = kern("pclass", f"k_pclass<{T}> (class marginals of pi (x) q)", "pi and q_J read once (live tiles)")
+        wsolve = os.environ.get("MMHN_WSOLVE", "1") != "0" and os.environ.get("MMHN_MSOLVE", "0") == "0"
+        ksolve = "k_wsolve" if wsolve else "k_psolve2"
+        rf_fwd = kern("psolve_fwd", f"{ksolve}<{T},false> (forward substitution solve of the joint problems"
+                      + (", window layout: a chain of patients per workgroup)" if wsolve else ", one workgroup per patient)"),
+                      "solution written once: the seeded half, 2^(k-1) x sizeof(dtype) per patient")
+        rf_adj = kern("psolve_adj", f"{ksolve}<{T},true> (adjoint substitution solve)", "solution written once")
+        rf_marg = kern("pclass", f"{'k_wclass' if wsolve else 'k_pclass'}<{T}> (class marginals of pi (x) q)", "pi and q_J read once (seeded halves)")
         rf_other = kern("other_solve", "k_tsolve / k_sweep (level-by-level solves of the marginal single-tumour problems)",
                         "per tile: solution written once (+ dense rhs / lidg vector reads)")
         live_bytes = (cnt["psolve_fwd"]["alg_bytes"] / max(cnt["psolve_fwd"]["launches"], 1)) if rf_fwd else None
@@ -338,7 +366,7 @@ def main():
             "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
-                       "solver": os.environ.get("MMHN_SOLVER", "substitution (k_psolve per patient, k_tsolve for the marginals)"),
+                       "solver": os.environ.get("MMHN_SOLVER", "substitution (k_wsolve: window layout, chains of patients; k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
             # dominant kernel of the timed step
             "roofline": dominant,

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(WROWS) void k_wclass(const Desc* __restrict__ descs
           T s = T(0);
 #pragma unroll
           for (int e = 0; e < QE; ++e) s += pv[e] * lo[e] + pv[QE + e] * hi[e];
-          acc[1 + i] += ((tid >> i) & 1) ? T(0) : s;
+          acc[1 + i] += s;                                     // (a row that has bit i never writes this slot: no select)
         }
 #pragma unroll
         for (int i = 0; i < WNXR; ++i) {
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(WROWS) void k_wclass(const Desc* __restrict__ descs
 #pragma unroll
           for (int b = LGQ; b < KC; ++b) {
             if (b < kC) {
-              const bool has = !((cp >> (b - LGQ)) & 1);
+              // (a column that has bit b never writes this slot: the sum it collects here is dropped, no select)
               const QT nq = *reinterpret_cast<const QT*>(qrow + (cp | (1 << (b - LGQ))) * QE);
 #pragma unroll
-              for (int e = 0; e < QE; ++e) ac[e][1 + b] += has ? pv[e] * nq[e] : T(0);
+              for (int e = 0; e < QE; ++e) ac[e][1 + b] += pv[e] * nq[e];
             }
           }
         }

@@ -19,7 +19,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r4"
 PMC = os.path.join(ROOT, "profiles", f"{TAG}_pmc")
 sys.path.insert(0, ROOT)
 
@@ -46,8 +46,9 @@ def main():
            "source": {"git_head": head, "csrc_sha16": csrc_sha16()}}
     ef, ew = per_launch("eval_f", "FETCH_SIZE"), per_launch("eval_w", "WRITE_SIZE")
     ek = {}
-    for name, prefix in (("psolve_fwd", "k_psolve2<double, false"), ("psolve_adj", "k_psolve2<double, true"), ("pclass", "k_pclass<double")):
-        kern = next((kname for kname in ef if kname.startswith(prefix)), None)      # (any DLOK instantiation)
+    for name, prefixes in (("psolve_fwd", ("k_wsolve<double, false", "k_psolve2<double, false")),
+                           ("psolve_adj", ("k_wsolve<double, true", "k_psolve2<double, true")), ("pclass", ("k_wclass<double", "k_pclass<double"))):
+        kern = next((kname for pre in prefixes for kname in ef if kname.startswith(pre)), None)
         if kern is None:
             continue
         b = (2 * ef[kern] + ew[kern]) * 1024
@@ -66,6 +67,20 @@ def main():
         kv[name]["moved_over_alg"] = kv[name]["bytes_per_launch"] / kv[name]["alg_bytes_per_launch"]
     out["kronvec"] = kv
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{TAG}_traffic.json"), "w"), indent=1)
+    # instruction counters of the same kernels (pass eval_i: SQ_INSTS_*), per launch
+    ck = {}
+    names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY")
+    per = {c: per_launch("eval_i", c) for c in names}
+    for name in ek:
+        kern = ek[name]["kernel"]
+        if kern in per["SQ_INSTS_VALU"]:
+            ck[name] = {c: per[c][kern] for c in names if kern in per[c]}
+            ck[name]["kernel"] = kern
+            ck[name]["waves_per_simd"] = 4 if kern.startswith(("k_wsolve", "k_wclass")) else 8
+    json.dump({"_comment": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY over "
+                           "scripts/eval_only.py 5000, mean per launch of the second evaluation; waves_per_simd from the launch geometry "
+                           "(k_wsolve / k_wclass: one 1024-thread workgroup per CU)",
+               "source": out["source"], "kernels": ck}, open(os.path.join(ROOT, "profiles", f"{TAG}_counters.json"), "w"), indent=1)
     print(json.dumps({k: round(v["bytes_per_patient"] / 1e6, 2) for k, v in ek.items()}))
     print(json.dumps({k: round(v["moved_over_alg"], 3) for k, v in kv.items()}))
 

@@ -17,19 +17,12 @@ cp $R/gpurun_out/prof_${tag}_kv/*/*kernel_stats.csv $R/gpurun_out/${tag}_kronvec
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_luad -- python3 $R/bench.py --workload luad --steps 20 --warmup 3 --no-cpu --no-extras > $R/gpurun_out/${tag}_luad_line.json 2> /dev/null
 cp $R/gpurun_out/prof_${tag}_luad/*/*kernel_stats.csv $R/gpurun_out/${tag}_luad_kernel_stats.csv
 mkdir -p $R/gpurun_out/${tag}_pmc
-for pass in "eval_f FETCH_SIZE eval_only.py 5000" "eval_w WRITE_SIZE eval_only.py 5000" "kv_f FETCH_SIZE kv_only.py" "kv_w WRITE_SIZE kv_only.py"; do
+for pass in "eval_f FETCH_SIZE eval_only.py 5000" "eval_w WRITE_SIZE eval_only.py 5000" "kv_f FETCH_SIZE kv_only.py" "kv_w WRITE_SIZE kv_only.py" \
+            "eval_i SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_WAIT_ANY eval_only.py 5000"; do
   set -- $pass
   name=$1; ctr=$2; shift; shift
   rm -rf /tmp/pmc_$name
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$name -- python3 $R/scripts/"$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc ${ctr//,/ } --output-format csv -d /tmp/pmc_$name -- python3 $R/scripts/"$@" > /dev/null 2>&1
   cp /tmp/pmc_$name/*/*counter_collection.csv $R/gpurun_out/${tag}_pmc/${name}_counter_collection.csv
 done
-# instruction mix of the two joint-solve implementations: default tile kernels, then MMHN_MSOLVE=1
-for v in 0 1; do
-  export MMHN_MSOLVE=$v
-  bash $R/scripts/pmc_eval.sh ${tag}_solve${v}_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" 5000 > $R/gpurun_out/${tag}_solve${v}_a.txt 2>&1
-  bash $R/scripts/pmc_eval.sh ${tag}_solve${v}_b "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_BUSY_CYCLES" 5000 > $R/gpurun_out/${tag}_solve${v}_b.txt 2>&1
-done
-unset MMHN_MSOLVE
-cat $R/gpurun_out/${tag}_solve0_a.txt $R/gpurun_out/${tag}_solve0_b.txt $R/gpurun_out/${tag}_solve1_a.txt $R/gpurun_out/${tag}_solve1_b.txt | grep "k_psolve2\|k_msolve" > $R/gpurun_out/${tag}_msolve_counters.txt
 ls -la $R/gpurun_out/${tag}_pmc
