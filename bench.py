@@ -331,13 +331,15 @@ def main():
             # half), against the fp64 vector peak; instruction counters from a separate PMC pass (profiles/r4_counters.json)
             if name in ("psolve_fwd", "psolve_adj") and a.workload == "full-k":
                 K = n - 1
-                fmas = unit_rows * (2.0 ** K) * (K / 2.0 + 1.0)
-                o["useful_fp64_fma_per_launch"] = fmas
-                o["fp64_fma_TFLOPs"] = 2.0 * fmas / avg_ms / 1e9
-                o["fp64_fma_frac"] = o["fp64_fma_TFLOPs"] / FP64_VECTOR_PEAK_TFLOPS
+                fmas = per_launch / esz * (K / 2.0 + 1.0)          # (states written by the launch) x (K / 2 + 1)
+                pk = FP64_VECTOR_PEAK_TFLOPS * (1.0 if a.dtype == "f64" else 2.0)
+                tag = "fp64" if a.dtype == "f64" else "fp32"
+                o[f"useful_{tag}_fma_per_launch"] = fmas
+                o[f"{tag}_fma_TFLOPs"] = 2.0 * fmas / avg_ms / 1e9
+                o[f"{tag}_fma_frac"] = o[f"{tag}_fma_TFLOPs"] / pk
                 ck = counters.get("kernels", {}).get(name)
                 if ck:
-                    states64 = unit_rows * (2.0 ** K) / 64.0
+                    states64 = per_launch / esz / 64.0
                     o["valu_wave_insts_per_64_states"] = ck["SQ_INSTS_VALU"] / states64
                     o["wave_insts_per_64_states"] = sum(ck.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                                                                                  "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) / states64
@@ -346,7 +348,7 @@ def main():
             return o
 
         T = "double" if a.dtype == "f64" else "float"
-        wsolve = os.environ.get("MMHN_WSOLVE", "1") != "0" and os.environ.get("MMHN_MSOLVE", "0") == "0"
+        wsolve = os.environ.get("MMHN_WSOLVE", "1") != "0" and a.dtype == "f64"
         ksolve = "k_wsolve" if wsolve else "k_psolve2"
         rf_fwd = kern("psolve_fwd", f"{ksolve}<{T},false> (forward substitution solve of the joint problems"
                       + (", window layout: a chain of patients per workgroup)" if wsolve else ", one workgroup per patient)"),

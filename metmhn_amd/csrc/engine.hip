@@ -30,7 +30,6 @@
 #include "../../include/metmhn_amd.h"
 #include "kernels.h"
 #include "small.h"
-#include "msolve.h"
 #include "wsolve.h"
 #include "wclass.h"
 #include "sampler.h"
@@ -112,10 +111,6 @@ struct Batch {
   int mk1p = 9;                  // bits the 256-thread class of the paired rows is sized for (spatient_class_maxk(1) or up to 10)
   std::vector<int> paired;       // patients with a joint problem (k_gather_marg runs over these only)
   DevArr<int> d_paired;
-  // matrix path (msolve.h): every joint problem of the batch qualifies -> the solves run in the class-sorted layout
-  bool mpath = false;
-  std::vector<MDesc> md;
-  DevArr<MDesc> d_md;
   std::vector<int> olist;        // joint problems that stay on the tile kernels
   DevArr<int> d_olist;
   // window path (wsolve.h): the same dispatch, 15 / 16 index bits on the chip
@@ -390,15 +385,11 @@ struct Engine : EngineBase {
   bool pair_small = true;       // MMHN_PAIR_SMALL=0: the two marginal problems of a paired row one after the other
   int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
   int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
-  int msolve_mode = 0;          // MMHN_MSOLVE=1: joint solves of per-patient batches in the class-sorted matrix layout (msolve.h:
-                                // second implementation, measured alternative - DESIGN.md 6); default: the tile kernels (k_psolve2)
   int wsolve_chain = 1;         // MMHN_WSOLVE_CHAIN=0: every window problem its own chain (the pipeline drains between patients)
   int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
   int wsolve_mode = 1;          // joint solves of per-patient batches in the window layout (wsolve.h); MMHN_WSOLVE=0: the tile
                                 // kernels (k_psolve2) for every problem, 2: window solves converted back to index order
   DevArr<T> piM, qM;            // matrix / window path: solutions in their own layout
-  DevArr<uint16_t> d_rowT, d_rankT;
-  DevArr<MUnit> d_units;
   int n_cu = 256;
   // counters
   mmhn_counters cnt{};
@@ -446,26 +437,13 @@ struct Engine : EngineBase {
       if (const char* sp = std::getenv("MMHN_ZEROCOPY")) zero_copy = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PREP_SPLIT")) prep_split_max = std::atoi(sp);
       if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
-      if (const char* ms = std::getenv("MMHN_MSOLVE")) msolve_mode = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
-      if (msolve_mode) wsolve_mode = 0;
       if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE_CHAIN")) wsolve_chain = std::atoi(ms);
-      std::vector<uint16_t> rt(MROWS), rk(MROWS);
-      matrix_rows(rt.data(), rk.data());
-      d_rowT.alloc(MROWS); d_rankT.alloc(MROWS);
-      HIPCHECK(hipMemcpy(d_rowT.p, rt.data(), MROWS * sizeof(uint16_t), hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(d_rankT.p, rk.data(), MROWS * sizeof(uint16_t), hipMemcpyHostToDevice));
-      std::vector<MUnit> mu(MW * MUPW);
-      matrix_units(mu.data());
-      d_units.alloc(mu.size());
-      HIPCHECK(hipMemcpy(d_units.p, mu.data(), mu.size() * sizeof(MUnit), hipMemcpyHostToDevice));
       hipDeviceProp_t prop;
       HIPCHECK(hipGetDeviceProperties(&prop, device));
       n_cu = std::max(1, prop.multiProcessorCount);
     }
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_msolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
@@ -743,24 +721,6 @@ struct Engine : EngineBase {
         return;
       }
     }
-    if (b.mpath) {
-      // matrix path: the solution is written once (seeded half)
-      const int nM = (int)b.md.size();
-      double bytes = 0;
-      for (const MDesc& m : b.md) bytes += 0.5 * (double)(1ll << b.dJ[m.prob].k) * sizeof(T);
-      T* ym = tr ? qM.p : piM.p;
-      timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-        const dim3 g((unsigned)std::min(nM, n_cu)), bk(MTHREADS);
-        const size_t lds = msolve_lds<T>();
-        if (tr) hipLaunchKernelGGL((k_msolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_md.p, nM, d_rowT.p, d_rankT.p, d_units.p, ym, tabJ.p, links.p, qS.p);
-        else hipLaunchKernelGGL((k_msolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_md.p, nM, d_rowT.p, d_rankT.p, d_units.p, ym, tabJ.p, links.p, qS.p);
-      });
-      hipLaunchKernelGGL((k_mconvert<T>), dim3(nM, 64), dim3(MROWS), 0, stream, b.d_dJ.p, b.d_md.p, d_rowT.p, ym, y);
-      HIPCHECK(hipGetLastError());
-      nold = (int)b.olist.size();
-      plist = b.d_olist.p;
-      if (nold == 0) return;
-    }
     if (b.all_multi && psolve_version == 2) {
       const long long spare = (80 * 1024 - 64) - (long long)psolve2_lds(mk);
       const int dl_cap = (int)std::max<long long>(0, std::min<long long>(PS_DL2, spare / (long long)sizeof(T)));
@@ -866,7 +826,7 @@ struct Engine : EngineBase {
         const int type = row[nc - 1];
         double el = 0;
         if (type == 3) {
-          el = (use_jacobi || msolve_mode || wsolve_mode ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
+          el = (use_jacobi || wsolve_mode == 2 ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
                (kp + 1) * std::ldexp(1.0, kp) + (km + 1) * std::ldexp(1.0, km) + (ke + 2) * std::ldexp(1.0, ke);
         } else {
           el = 4.0 * std::ldexp(1.0, (type == 2 ? km : kp) + 1);
@@ -925,7 +885,7 @@ struct Engine : EngineBase {
       auto footprint = [&](long long vJ, long long vS, long long as, long long tabs, size_t nJp, size_t nSp, size_t npat) {
         const size_t small = (nSp * (size_t)(N * N + 64 + 1) + nJp * (size_t)(3 * N * N + 3 * N + 64)) * sizeof(T) +
                              nJp * sizeof(JLink<T>) + npat * ((size_t)stride() + 1) * sizeof(double) + npat * 2 * sizeof(T);
-        return (size_t)((use_jacobi || msolve_mode || wsolve_mode ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
+        return (size_t)((use_jacobi || wsolve_mode == 2 ? 4 : 2) * vJ + 4 * vS + as + tabs) * sizeof(T) + small;
       };
       const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
                                     cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
@@ -979,19 +939,7 @@ struct Engine : EngineBase {
       b.all_multi = !b.dJ.empty();
       for (const Desc& dj : b.dJ)
         if (!(dj.seedbit >= TB && popc(dj.pairP) <= TB)) b.all_multi = false;
-      b.md.clear();
       b.olist.clear();
-      b.mpath = msolve_mode != 0 && !use_jacobi && (int)b.dJ.size() >= psolve_min && b.all_multi;
-      if (b.mpath) {
-        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
-          if (!matrix_ok(b.dJ[pj], MCfg<T>::NML, MCfg<T>::KD)) { b.olist.push_back((int)pj); continue; }
-          MDesc m = make_mdesc(b.dJ[pj], (int)pj);
-          b.md.push_back(m);
-        }
-        if (b.md.empty()) b.mpath = false;
-        up(b.d_md, b.md);
-        up(b.d_olist, b.olist);
-      }
       b.wd.clear();
       b.wpath = wsolve_mode != 0 && !use_jacobi && (int)b.dJ.size() >= psolve_min && b.all_multi;
       if (b.wpath) {
@@ -1129,7 +1077,7 @@ struct Engine : EngineBase {
       mvJ = std::max(mvJ, b.vecJ); mvS = std::max(mvS, b.vecS);
       mZ = std::max<size_t>(mZ, (size_t)zarena_elems((long long)b.dJ.size(), b.asize, N));
       mtJ = std::max(mtJ, b.tabJ); mtS = std::max(mtS, b.tabS);
-      if (b.mpath || (b.wpath && !b.wdirect)) mvM = std::max(mvM, b.vecJ);
+      if (b.wpath && !b.wdirect) mvM = std::max(mvM, b.vecJ);
       mnJ = std::max(mnJ, b.dJ.size()); mnS = std::max(mnS, b.dS.size()); mp = std::max(mp, b.pats.size());
     }
     pi.alloc(mvJ); qJ.alloc(mvJ);

@@ -49,8 +49,11 @@ constexpr int WNXR = WKR - WTB;
 template <typename T> struct WCfg;
 // RB: column bits of a block, HB: blocks of a window, KC: most column-class bits (their rate table lives in LDS),
 // PAD: elements between the table rows of two external column settings (16 bytes: the lanes of a wave differ in it)
-template <> struct WCfg<double> { static constexpr int RB = 2, HB = 2, KC = 9, PAD = 2; };
-template <> struct WCfg<float> { static constexpr int RB = 3, HB = 3, KC = 10, PAD = 4; };
+// ON: the engine uses the window path for this dtype.  fp32 (BASELINE configs[4]: k = 25, nine external bits with at most
+// ten column bits in the LDS tables) measured slower than the tile kernels (5.3 s against 4.5 s per 10 000-patient
+// evaluation): its kernels are kept compiling, the engine leaves fp32 cohorts to k_psolve2 / k_pclass.
+template <> struct WCfg<double> { static constexpr int RB = 2, HB = 2, KC = 9, PAD = 2; static constexpr bool ON = true; };
+template <> struct WCfg<float> { static constexpr int RB = 3, HB = 2, KC = 10, PAD = 4; static constexpr bool ON = false; };
 
 // static description of one joint problem on the window path (host-built, set_cohort)
 struct WDesc {

@@ -1,5 +1,5 @@
-// Joint triangular solves in the WINDOW layout (round 4): the class-sorted matrix formulation of msolve.h with
-// 15 (fp64) / 16 (fp32) of a patient's index bits on the chip instead of 12.
+// Joint triangular solves in the WINDOW layout (round 4): a class-sorted matrix formulation with 14 - 15 of a patient's
+// index bits on the chip instead of the 12 of a tile (kernels.h: k_psolve2).
 //
 // On the seed = 1 half of a paired patient's space the operator is a Kronecker sum, D - Q = A_R (+) A_C over the two
 // tumour classes (reference: metmhn/jx/likelihood.py:231-262 solves it with k+1 Jacobi sweeps of
@@ -30,14 +30,27 @@
 // (Measured and dropped: a block as two planes of 16 bytes per row - no line requested by two instructions, but runs
 // half as long: adjoint 18.6 -> 22.9 ms; a one-dword LDS-DMA touch of the next step's external rows: +2.5 / +6 ms.)
 #pragma once
-#include "msolve.h"
+#include "kernels.h"
 #include "wlayout.h"
 
 namespace mmhn {
 
+constexpr int MKE = 9;                 // most paired events (eq block of 2^MKE states in LDS)
+
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS only, vector memory stays in flight
+  __builtin_amdgcn_s_barrier();
+}
+
+template <typename T> __device__ __forceinline__ T fma_m(T a, T b, T c);
+template <> __device__ __forceinline__ double fma_m<double>(double a, double b, double c) { return fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_m<float>(float a, float b, float c) { return fmaf(a, b, c); }
+
+template <int I> struct IC { static constexpr int value = I; };
+
 template <typename T>
 inline bool window_ok(const Desc& d) {
-  if (d.mode != JOINT || d.seedbit != d.k - 1) return false;
+  if (!WCfg<T>::ON || d.mode != JOINT || d.seedbit != d.k - 1) return false;
   const int kP = popc(d.maskP), kM = popc(d.maskM);
   const int kR = kP >= kM ? kP : kM, kC = kP >= kM ? kM : kP;
   return kR >= WTB && kR <= WKR && kC >= WCfg<T>::RB + WCfg<T>::HB && kC <= WCfg<T>::KC && popc(d.pairP) <= MKE;

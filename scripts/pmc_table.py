@@ -9,7 +9,7 @@ import sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
     rows += list(csv.DictReader(open(f)))
-want = sys.argv[2:] or ["k_wsolve", "k_wconvert", "k_msolve", "k_psolve", "k_pclass", "k_sweep", "k_tsolve", "k_grad_rows", "k_spatient"]
+want = sys.argv[2:] or ["k_wsolve", "k_wclass", "k_wconvert", "k_psolve", "k_pclass", "k_sweep", "k_tsolve", "k_grad_rows", "k_spatient"]
 vals = collections.defaultdict(list)
 for r in rows:
     k = r["Kernel_Name"].split("(")[0].replace("void mmhn::", "")

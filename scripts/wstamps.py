@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a k_msolve step spends its cycles (diagnostic build -DMMHN_STAMPS; wave 0 of every workgroup):
-    MMHN_LIB=build_ab/libstamps.so python scripts/mstamps.py [patients]"""
+"""Where a k_wsolve step spends its cycles (diagnostic build -DMMHN_STAMPS; wave 0 of every workgroup):
+    MMHN_LIB=build_ab/lib_stamps.so python scripts/wstamps.py [patients]"""
 import ctypes as C
 import os
 import sys
@@ -25,11 +25,8 @@ e.reset_counters()
 e.cohort_sums(lt, dp, dm)
 lib.mmhn_debug_stamps(e.h, out, 1)
 v = np.array(out[:])
-names = ["0 take (wait for own earlier blocks)", "1 issue next unit's loads", "2 thread-bit terms (LDS)", "3 rhs + block solve",
-         "4 stores", "5 barrier", "6 per-patient setup", "7 eq block / end"]
-if os.environ.get("MMHN_MSOLVE", "0") == "0":                  # k_wsolve (wsolve.h)
-    names = ["0 request ext 0,1 + lane moves (DPP)", "1 take ext 0,1 (wait), request ext 2,3", "2 wave moves (ring)",
-             "3 window moves, take ext 2,3", "4 rhs, block solve, stores", "5 barrier", "6 begin of a pass", "7 patient enters / leaves"]
+names = ["0 request ext 0,1 + lane moves (DPP)", "1 take ext 0,1 (wait), request ext 2,3", "2 wave moves (ring)",
+         "3 window moves, take ext 2,3", "4 rhs, block solve, stores", "5 barrier", "6 begin of a pass", "7 patient enters / leaves"]
 for half, nm in ((0, "forward"), (8, "adjoint")):
     tot = v[half:half + 8].sum()
     print(f"{nm}: {tot / P:.0f} cycles per patient (wave 0), shares:")

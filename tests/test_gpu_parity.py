@@ -861,49 +861,6 @@ def test_split_evaluation_and_error_order(golden):
 
 
 @pytest.mark.gpu
-def test_matrix_layout_solves_match_cpu_port(monkeypatch):
-    """MMHN_MSOLVE=1: the joint solves in the class-sorted matrix layout (csrc/msolve.h - rows of one popcount level
-    in lock step, level pipeline through LDS, the thread's own history for the serial bits) against
-    oracle/metmhn_fast.c on n = k = 20 patients, and against the tile kernels on a cohort that mixes shapes the
-    matrix path takes with shapes it leaves to the tile kernels (per-problem dispatch)."""
-    from oracle import cref
-    from metmhn_amd import Engine, synthetic
-    n = 20
-    lt, dp, dm = synthetic.random_params(n)
-    dat = synthetic.full_k_cohort(n, 12, seed=2000 + n)
-    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
-    monkeypatch.setenv("MMHN_PSOLVE_MIN", "1")
-    monkeypatch.setenv("MMHN_MSOLVE", "1")
-    e = Engine(n)
-    e.set_cohort(dat)
-    r = e.patient_grads(lt, dp, dm)
-    e.close()
-    np.testing.assert_allclose(r[0], lp, rtol=1e-10)
-    np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
-    np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
-    np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
-    rows = [
-        _row(n, range(16), [17, 18, 19], 1),                    # 16 major bits: beyond the matrix path's left-over bits
-        _row(n, range(13), range(10, 16), 2),                   # kP = 13, kM = 6, three pairs
-        _row(n, list(range(0, 20, 2)) + [1], range(1, 17, 2), 0),   # kP = 11, kM = 8
-        _row(n, range(10), range(5, 14), 1),                    # kP = 10, kM = 9
-        _row(n, range(9), range(6, 19), 0),                     # kM = 13 major, pairs
-        _row(n, range(12), [12, 13], 0),                        # k = 15: too few minor bits for the matrix path
-    ]
-    dat = np.array(rows, dtype=np.int8)
-    res = []
-    for ms in ("1", "0"):
-        monkeypatch.setenv("MMHN_MSOLVE", ms)
-        e = Engine(n)
-        e.set_cohort(dat)
-        res.append(e.patient_grads(lt, dp, dm))
-        e.close()
-    for x, y in zip(*res):
-        assert np.isfinite(x).all()
-        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
-
-
-@pytest.mark.gpu
 def test_batched_kronvec_at_benchmarked_shape():
     """mmhn_kronvec_batched = the launch mmhn_bench_kronvec times (k_kv: 256 tiles per vector, 8 tile bits, neighbour
     pipeline, scalar-unit U rows), at the benchmarked shape n = k = 20 with B = 4 random vectors.  The device output
