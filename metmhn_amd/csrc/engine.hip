@@ -118,6 +118,7 @@ struct Batch {
   bool wdirect = false;          // the consumers read the window layout in place (no conversion to index order)
   std::vector<WDesc> wd;         // sorted by shape; the state vectors of consecutive entries lie back to back
   DevArr<WDesc> d_wd;
+  int wnx = -1;                  // external bits of every window problem of the batch, -1: they differ
   std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
   DevArr<WChain> d_wchains;
   // the few problems the window path leaves over: tile-level solver (one patient walking its tiles alone takes ~2 ms)
@@ -446,6 +447,8 @@ struct Engine : EngineBase {
     }
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -702,8 +705,13 @@ struct Engine : EngineBase {
         const int nch = (int)b.wchains.size();
         const dim3 g((unsigned)std::min(nch, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
         const size_t lds = wsolve_lds<T>();
-        if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p);
-        else hipLaunchKernelGGL((k_wsolve<T, false>), g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p);
+#define WS_ARGS g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p
+        // (a batch whose chains all have the same number of external bits - every k = 20 cohort: 5 - runs the instantiation
+        // that knows it at compile time)
+        if (b.wnx == 5) { if (tr) hipLaunchKernelGGL((k_wsolve<T, true, 5>), WS_ARGS); else hipLaunchKernelGGL((k_wsolve<T, false, 5>), WS_ARGS); }
+        else if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), WS_ARGS);
+        else hipLaunchKernelGGL((k_wsolve<T, false>), WS_ARGS);
+#undef WS_ARGS
       });
       if (!b.wdirect) {
         hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
@@ -959,6 +967,8 @@ struct Engine : EngineBase {
         for (int pj : b.olist) { b.dJ[pj].off = off; off += 1ll << b.dJ[pj].k; }
         REQUIRE(off == b.vecJ, "window path: offsets of the joint problems do not add up");
         const int nW = (int)b.wd.size();
+        b.wnx = b.wd[0].nXc + b.wd[0].nXr;
+        for (const WDesc& w : b.wd) if (w.nXc + w.nXr != b.wnx) b.wnx = -1;
         const int groups = std::max(1, wsolve_wgs > 0 ? wsolve_wgs : n_cu);
         const int per = (nW + groups - 1) / groups;
         for (int i0 = 0; i0 < nW;) {

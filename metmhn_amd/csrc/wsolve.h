@@ -163,7 +163,9 @@ constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
 //            617-618), the seed = 0 lattice follows the seeded half.
 // Persistent: workgroup b takes chains b, b + gridDim.x, ...
 // ------------------------------------------------------------------------------------
-template <typename T, bool TR>
+// NXT >= 0: the number of external bits of every chain of the launch, as a compile-time constant (the step loop then has no
+// scalar branches on it); NXT < 0: read per chain
+template <typename T, bool TR, int NXT = -1>
 __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs, const WDesc* __restrict__ wds,
                                                   const WChain* __restrict__ chains, int nchains,
                                                   T* y, const T* __restrict__ tab,
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     const WDesc& w0 = wds[first];
     const Desc& d0 = descs[w0.prob];
     const int k = sgpr(d0.k), kR = sgpr(w0.kR), kC = sgpr(w0.kC), nXc = sgpr(w0.nXc), nXr = sgpr(w0.nXr);
-    const int nX = nXc + nXr;
+    const int nX = NXT >= 0 ? NXT : nXc + nXr;
     const int seedb = k - 1;
     const long long half = 1ll << (k - 1);
     const long long ybase = sgpr64(d0.off);                    // patient j of the chain: y + ybase + (j << k)
