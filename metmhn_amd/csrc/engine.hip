@@ -447,8 +447,8 @@ struct Engine : EngineBase {
     }
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false, WCfg<T>::NXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true, WCfg<T>::NXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -706,9 +706,9 @@ struct Engine : EngineBase {
         const dim3 g((unsigned)std::min(nch, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
         const size_t lds = wsolve_lds<T>();
 #define WS_ARGS g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p
-        // (a batch whose chains all have the same number of external bits - every k = 20 cohort: 5 - runs the instantiation
+        // (a batch whose chains all have the same number of external bits - every k = 20 cohort: 5, k = 25: 9 - runs the instantiation
         // that knows it at compile time)
-        if (b.wnx == 5) { if (tr) hipLaunchKernelGGL((k_wsolve<T, true, 5>), WS_ARGS); else hipLaunchKernelGGL((k_wsolve<T, false, 5>), WS_ARGS); }
+        if (b.wnx == WCfg<T>::NXT) { if (tr) hipLaunchKernelGGL((k_wsolve<T, true, WCfg<T>::NXT>), WS_ARGS); else hipLaunchKernelGGL((k_wsolve<T, false, WCfg<T>::NXT>), WS_ARGS); }
         else if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), WS_ARGS);
         else hipLaunchKernelGGL((k_wsolve<T, false>), WS_ARGS);
 #undef WS_ARGS
@@ -825,6 +825,7 @@ struct Engine : EngineBase {
     // a cohort that does not fit the workspace is cut into batches of about equal size (not: full ones and a small
     // remainder - every batch should be large enough for the per-patient kernels): soft target per batch
     double soft_target = 0;
+    long long pat_target = 0;
     {
       double total = 0;
       for (long long r = 0; r < np; ++r) {
@@ -843,6 +844,12 @@ struct Engine : EngineBase {
       }
       const double nb = std::ceil(total / (double)std::max<size_t>(ws_limit, 1));
       soft_target = nb > 1 ? total / nb * 1.02 : 0;
+      // the per-patient kernels take one patient per CU at a time: a batch of 400 costs two rounds of 256.  Batches of a cut
+      // cohort hold a multiple of the CU count (rounded down: more, fuller rounds)
+      if (nb > 1 && np > 0) {
+        const double per_batch = (double)ws_limit / (total / (double)np);
+        if (per_batch >= (double)n_cu) pat_target = (long long)(per_batch / n_cu) * n_cu;
+      }
     }
     std::vector<int8_t> st(2 * n + 2);
     for (long long r = 0; r < np; ++r) {
@@ -898,7 +905,8 @@ struct Engine : EngineBase {
       const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
                                     cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
       const size_t have = footprint(cur.vecJ, cur.vecS, cur.asize, cur.tabJ + cur.tabS, cur.dJ.size(), cur.dS.size(), cur.pats.size());
-      if (!cur.pats.empty() && (need > ws_limit || (soft_target > 0 && (double)have >= soft_target))) flush();
+      if (!cur.pats.empty() && (need > ws_limit || (pat_target > 0 ? (long long)cur.pats.size() >= pat_target
+                                                                         : (soft_target > 0 && (double)have >= soft_target)))) flush();
       if (hasJ) {
         dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
         cur.vecJ += 1ll << dj.k; cur.asize += a_size(dj);
@@ -981,6 +989,24 @@ struct Engine : EngineBase {
           while (len < maxlen && i0 + len < nW && b.wd[i0 + len].kR == w.kR && b.wd[i0 + len].kC == w.kC && (i0 + len) % per != 0) ++len;
           b.wchains.push_back(WChain{i0, len});
           i0 += len;
+        }
+        if ((int)b.wchains.size() > groups) {
+          // more chains than workgroups (shape changes cut chains short): workgroup g takes the entries g, g + groups, ... -
+          // deal the chains longest first to the least loaded workgroup, empty entries fill the rounds
+          std::vector<WChain> srt = b.wchains;
+          std::stable_sort(srt.begin(), srt.end(), [](const WChain& x, const WChain& y) { return x.count > y.count; });
+          std::vector<std::vector<WChain>> mine((size_t)groups);
+          std::vector<int> load((size_t)groups, 0);
+          for (const WChain& c : srt) {
+            const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            mine[g].push_back(c);
+            load[g] += c.count;
+          }
+          size_t rounds = 0;
+          for (const auto& m : mine) rounds = std::max(rounds, m.size());
+          b.wchains.assign(rounds * (size_t)groups, WChain{0, 0});
+          for (int g = 0; g < groups; ++g)
+            for (size_t r = 0; r < mine[g].size(); ++r) b.wchains[r * (size_t)groups + g] = mine[g][r];
         }
         up(b.d_wd, b.wd);
         up(b.d_olist, b.olist);

@@ -30,7 +30,7 @@ template <typename T>
 __global__ __launch_bounds__(WROWS) void k_wclass(const Desc* __restrict__ descs, const WDesc* __restrict__ wds, int nw,
                                                   const T* __restrict__ p, const T* __restrict__ q, T* A) {
   using C = WCfg<T>;
-  constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, KC = C::KC;
+  constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, KC = C::KC, WNXR = C::KR - WTB;
   constexpr int QE = 16 / (int)sizeof(T), LGQ = QE == 2 ? 1 : 2, NQ = NC / QE;
   constexpr int CHE = WClass<T>::CHE;
   typedef T VecT __attribute__((ext_vector_type(NC)));

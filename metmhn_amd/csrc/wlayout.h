@@ -43,17 +43,29 @@ __host__ __device__ inline uint32_t pdep32(uint32_t v, uint32_t mask) {
 
 constexpr int WLB = 6, WWB = 4, WTB = WLB + WWB;   // lane bits, wave bits, thread bits
 constexpr int WROWS = 1 << WTB;                    // rows of a block = threads of a workgroup
-constexpr int WKR = 15;                            // most row-class bits (five beyond the thread bits)
-constexpr int WNXR = WKR - WTB;
+constexpr int WMAXB = 20;                          // array bound of the per-bit lists of a WDesc
 
 template <typename T> struct WCfg;
-// RB: column bits of a block, HB: blocks of a window, KC: most column-class bits (their rate table lives in LDS),
+// RB: column bits of a block, HB: blocks of a window, KC: most column-class bits (their tables live in LDS),
+// KR: most row-class bits (the ten thread bits + external row bits), KE: most paired events (the seed = 0 lattice of
+// 2^KE states is solved in LDS),
+// NXT: the number of external bits the solve kernel is also built for as a compile-time constant (k = 20 fp64: 5, k = 25 fp32: 9),
 // PAD: elements between the table rows of two external column settings (16 bytes: the lanes of a wave differ in it)
-// ON: the engine uses the window path for this dtype.  fp32 (BASELINE configs[4]: k = 25, nine external bits with at most
-// ten column bits in the LDS tables) measured slower than the tile kernels (5.3 s against 4.5 s per 10 000-patient
-// evaluation): its kernels are kept compiling, the engine leaves fp32 cohorts to k_psolve2 / k_pclass.
-template <> struct WCfg<double> { static constexpr int RB = 2, HB = 2, KC = 9, PAD = 2; static constexpr bool ON = true; };
-template <> struct WCfg<float> { static constexpr int RB = 3, HB = 2, KC = 10, PAD = 4; static constexpr bool ON = false; };
+// FACT: the rates of the column-class events are kept as two factors, [event][window setting] x [event][external column
+//       setting] (one more multiply per fetched rate vector, 8 KB instead of kC * 2^(kC-1) entries): what lets twelve
+//       column bits fit.  fp64 keeps the full tables (nine column bits cover every k = 20 shape).
+// ON: the engine uses the window path for this dtype.
+template <> struct WCfg<double> {
+  static constexpr int RB = 2, HB = 2, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = 5;
+  static constexpr bool FACT = false, ON = true;
+};
+#ifndef MMHN_WF32
+#define MMHN_WF32 1   // build switch: 0 = fp32 cohorts on the tile kernels (k_psolve2 / k_pclass) only
+#endif
+template <> struct WCfg<float> {
+  static constexpr int RB = 3, HB = 2, KC = 12, KR = 18, KE = 12, PAD = 4, NXT = 9;
+  static constexpr bool FACT = true, ON = MMHN_WF32 != 0;
+};
 
 // static description of one joint problem on the window path (host-built, set_cohort)
 struct WDesc {
@@ -63,9 +75,9 @@ struct WDesc {
   uint32_t rowmask, colmask; // natural index bits of the two classes
   uint32_t pairRowC;         // compact row bits whose event is also active in the other tumour
   uint32_t loneRowC;         // compact row bits whose partner slot is inactive
-  int8_t rb[16];             // natural bit of row bit i
-  int8_t cb[16];             // natural bit of column bit i
-  int8_t prt[16];            // column bit of the partner of row bit i, -1: none
+  int8_t rb[WMAXB];          // natural bit of row bit i
+  int8_t cb[WMAXB];          // natural bit of column bit i
+  int8_t prt[WMAXB];         // column bit of the partner of row bit i, -1: none
 };
 
 // rows of a block sorted by lane-level: rho(w, l) = 16 * (rows of lower levels) + w * C(6, m) + rank of l in its level

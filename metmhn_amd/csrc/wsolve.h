@@ -35,7 +35,6 @@
 
 namespace mmhn {
 
-constexpr int MKE = 9;                 // most paired events (eq block of 2^MKE states in LDS)
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS only, vector memory stays in flight
@@ -48,12 +47,14 @@ template <> __device__ __forceinline__ float fma_m<float>(float a, float b, floa
 
 template <int I> struct IC { static constexpr int value = I; };
 
+template <typename T> inline bool wtab_fits(int kR, int kC);
 template <typename T>
 inline bool window_ok(const Desc& d) {
   if (!WCfg<T>::ON || d.mode != JOINT || d.seedbit != d.k - 1) return false;
   const int kP = popc(d.maskP), kM = popc(d.maskM);
   const int kR = kP >= kM ? kP : kM, kC = kP >= kM ? kM : kP;
-  return kR >= WTB && kR <= WKR && kC >= WCfg<T>::RB + WCfg<T>::HB && kC <= WCfg<T>::KC && popc(d.pairP) <= MKE;
+  return kR >= WTB && kR <= WCfg<T>::KR && kC >= WCfg<T>::RB + WCfg<T>::HB && kC <= WCfg<T>::KC && popc(d.pairP) <= WCfg<T>::KE &&
+         wtab_fits<T>(kR, kC);
 }
 template <typename T>
 inline WDesc make_wdesc(const Desc& d, int prob) {
@@ -125,34 +126,62 @@ struct WPInfo {                      // what a lane needs to know about the pati
   long long soff[2];                 // transposed: start of the upper half of q_S of the row part / column part, -1: none
   T cst[2];                          //             its constant (JLink)
   uint32_t pairRowC, loneRowC;       // forward: compact row bits with / without a partner slot
-  int prt[16];                       //          column bit of the partner of row bit i
+  int prt[WMAXB];                    //          column bit of the partner of row bit i
 };
+
+// offsets (elements) of one patient's tables in LDS.  Full tables (fp64): compile-time constants, sized for the largest
+// shape.  Factored tables (fp32): packed per shape (a chain has one shape) - twelve column bits need a big diagonal table,
+// eighteen row bits a big external-row table, never both (window_ok checks the total).
+struct WOff { int oFx, XS, oDC, oLr, oUr, oEr, ES, oSe, size; };
 
 template <typename T>
 struct WLds {
   using C = WCfg<T>;
-  static constexpr int NC = 1 << C::RB, WB = C::RB + C::HB, WIN = 1 << WB, NXCM = C::KC - WB;
+  static constexpr int NC = 1 << C::RB, WB = C::RB + C::HB, WIN = 1 << WB, NXCM = C::KC - WB, WKR = C::KR, MKE = C::KE;
   // rates of the column-class events, only for the column sets that do not contain the event (half of them):
   //   bit b < WB (inside a window): [external column setting Tx][window setting with bit b squeezed out] - SZLO entries
   //   bit b >= WB (external):       [Tx with bit b - WB squeezed out][window setting]                     - SZHI entries
   static constexpr int LOS = WIN / 2 + C::PAD, HIS = WIN + C::PAD;     // row strides (the lanes of a wave differ in Tx: banks)
   static constexpr int SZLO = (1 << NXCM) * LOS, SZHI = (NXCM > 0 ? (1 << (NXCM - 1)) : 1) * HIS;
+  // FACT: rate = Fw[event][window setting] * Fx[event][external column setting] (the event's own bit is skipped in both)
   static constexpr int oRh = 0;
+  static constexpr int oFw = oRh, oFx = oFw + C::KC * WIN;
   static constexpr int oDC = oRh + WB * SZLO + NXCM * SZHI;            // [Tx][window setting] column part of the diagonal
   static constexpr int oLr = oDC + (1 << NXCM) * HIS;                  // [WKR][64] row-bit rate: product over the lane bits
   static constexpr int oUr = oLr + WKR * 64;                           // [WKR][16] ... base rate and the wave bits
   static constexpr int oEr = oUr + WKR * 16;                           // [WKR][32] ... the external row bits
   static constexpr int oSe = oEr + WKR * 32;                           // [2^ke] forward: seeding inflow of eq state e
-  static constexpr int TABSZ = (oSe + (1 << MKE) + 3) / 4 * 4;         // one patient's tables
   static constexpr int ring = 0;                                        // [2][NC * sizeof(T) / 16][WROWS] 16-byte pieces
   static constexpr int tab0 = ring + 2 * NC * WROWS;                    // two patients' tables
+  static constexpr int LDSMAX = 160 * 1024;
+  static constexpr int TABSZ = C::FACT ? ((LDSMAX - 64 - 2 * (int)sizeof(WPInfo<T>)) / (int)sizeof(T) - tab0) / 2 / 4 * 4
+                                       : (oSe + (1 << MKE) + 3) / 4 * 4;  // one patient's tables
   static constexpr int end = tab0 + 2 * TABSZ;
   // while a patient enters or leaves the pipeline the ring is dead: the effect table thc [k][k] and the eq-block
   // solution e0 [2^ke] live there
   static constexpr int thc = ring, e0 = ring + (MAXK * MAXK + 3) / 4 * 4;
   static constexpr size_t bytes = (size_t)end * sizeof(T) + 2 * sizeof(WPInfo<T>) + 64;
   static_assert(e0 + (1 << MKE) <= tab0, "event scratch fits the ring");
+  static_assert(bytes <= (size_t)LDSMAX, "two patients' tables and the ring fit the LDS of a CU");
+  __host__ __device__ static WOff offsets(int kR, int kC) {
+    WOff o;
+    if (C::FACT) {
+      const int nXc = kC - WB, nXr = kR - WTB;
+      o.oFx = oFw + kC * WIN; o.XS = 1 << nXc;
+      o.oDC = o.oFx + (kC << nXc);
+      o.oLr = o.oDC + (1 << nXc) * HIS;
+      o.oUr = o.oLr + kR * 64;
+      o.oEr = o.oUr + kR * 16; o.ES = 1 << nXr;
+      o.oSe = o.oEr + (kR << nXr);
+      o.size = o.oSe + (1 << MKE);
+    } else {
+      o.oFx = oFx; o.XS = 1 << NXCM; o.oDC = oDC; o.oLr = oLr; o.oUr = oUr; o.oEr = oEr; o.ES = 32; o.oSe = oSe; o.size = TABSZ;
+    }
+    return o;
+  }
 };
+template <typename T>
+inline bool wtab_fits(int kR, int kC) { return WLds<T>::offsets(kR, kC).size <= WLds<T>::TABSZ; }
 template <typename T>
 constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
 
@@ -205,10 +234,17 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   for (int ci = blockIdx.x; ci < nchains; ci += gridDim.x) {
     STAMP_START;
     const int first = sgpr(chains[ci].start), npat = sgpr(chains[ci].count);
+    if (npat == 0) continue;                                   // (a filler entry of the host's chain deal)
     const WDesc& w0 = wds[first];
     const Desc& d0 = descs[w0.prob];
     const int k = sgpr(d0.k), kR = sgpr(w0.kR), kC = sgpr(w0.kC), nXc = sgpr(w0.nXc), nXr = sgpr(w0.nXr);
     const int nX = NXT >= 0 ? NXT : nXc + nXr;
+    // table offsets: constants with the full tables, per shape with the factored ones
+    const WOff wo = L::offsets(kR, kC);
+    const int oFx = C::FACT ? sgpr(wo.oFx) : L::oFx, XS = C::FACT ? sgpr(wo.XS) : (1 << L::NXCM);
+    const int oDC = C::FACT ? sgpr(wo.oDC) : L::oDC, oLr = C::FACT ? sgpr(wo.oLr) : L::oLr, oUr = C::FACT ? sgpr(wo.oUr) : L::oUr;
+    const int oEr = C::FACT ? sgpr(wo.oEr) : L::oEr, ES = C::FACT ? sgpr(wo.ES) : 32, oSe = C::FACT ? sgpr(wo.oSe) : L::oSe;
+    (void)oFx; (void)XS;
     const int seedb = k - 1;
     const long long half = 1ll << (k - 1);
     const long long ybase = sgpr64(d0.off);                    // patient j of the chain: y + ybase + (j << k)
@@ -277,8 +313,24 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       __syncthreads();                                         // every wave has left the steps before: ring and buffer j & 1 are free
       load_thc(d);
       __syncthreads();
+      if constexpr (C::FACT) {
+        for (uint32_t e = tid; e < ((uint32_t)kC << WB); e += WROWS) {
+          const int b = (int)(e >> WB), nb = wd.cb[b];
+          const uint32_t u = e & (uint32_t)(WIN - 1);
+          T r = thc[nb * k + nb];
+          for (int i = 0; i < WB; ++i) if (i != b && ((u >> i) & 1u)) r *= thc[nb * k + wd.cb[i]];
+          tb[L::oFw + e] = r;
+        }
+        for (uint32_t e = tid; e < ((uint32_t)kC << nXc); e += WROWS) {
+          const int b = (int)(e >> nXc), nb = wd.cb[b];
+          const uint32_t u = e & mXc;
+          T r = T(1);
+          for (int i = 0; i < nXc; ++i) if (WB + i != b && ((u >> i) & 1u)) r *= thc[nb * k + wd.cb[WB + i]];
+          tb[oFx + b * XS + u] = r;
+        }
+      }
       // rates of the column-class events from the column sets without the event
-      for (uint32_t e = tid; e < ((uint32_t)kC << (kC - 1)); e += WROWS) {
+      for (uint32_t e = tid; !C::FACT && e < ((uint32_t)kC << (kC - 1)); e += WROWS) {
         const int b = (int)(e >> (kC - 1)), nb = wd.cb[b];
         const uint32_t u = e & ((1u << (kC - 1)) - 1u);
         const uint32_t Tc = ((u >> b) << (b + 1)) | (u & ((1u << b) - 1u));      // the column set (bit b clear)
@@ -289,24 +341,24 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         else idx = WB * SZLO + (b - WB) * SZHI + squeeze(Tc >> WB, b - WB) * HIS + (Tc & (uint32_t)(WIN - 1));
         tb[L::oRh + idx] = r;
       }
-      for (uint32_t e = tid; e < (1u << kC); e += WROWS) tb[L::oDC + (e >> WB) * HIS + (e & (uint32_t)(WIN - 1))] = dCg[e];
+      for (uint32_t e = tid; e < (1u << kC); e += WROWS) tb[oDC + (e >> WB) * HIS + (e & (uint32_t)(WIN - 1))] = dCg[e];
       for (int e = tid; e < kR * 64; e += WROWS) {
         const int i = e >> 6, l = e & 63, nb = wd.rb[i];
         T r = T(1);
         for (int q = 0; q < WLB; ++q) if (q != i && ((l >> q) & 1)) r *= thc[nb * k + wd.rb[q]];
-        tb[L::oLr + e] = r;
+        tb[oLr + e] = r;
       }
       for (int e = tid; e < kR * 16; e += WROWS) {
         const int i = e >> 4, u = e & 15, nb = wd.rb[i];
         T r = thc[nb * k + nb];
         for (int q = 0; q < WWB; ++q) if (WLB + q != i && ((u >> q) & 1)) r *= thc[nb * k + wd.rb[WLB + q]];
-        tb[L::oUr + e] = r;
+        tb[oUr + e] = r;
       }
-      for (int e = tid; e < kR * 32; e += WROWS) {
-        const int i = e >> 5, u = e & 31, nb = wd.rb[i];
+      for (int e = tid; e < kR * ES; e += WROWS) {
+        const int i = C::FACT ? e >> nXr : e >> 5, u = e & (ES - 1), nb = wd.rb[i];
         T r = T(1);
         for (int q = 0; q < nXr; ++q) if (WTB + q != i && ((u >> q) & 1)) r *= thc[nb * k + wd.rb[WTB + q]];
-        tb[L::oEr + e] = r;
+        tb[oEr + e] = r;
       }
       if (tid == 0) {
         WPInfo<T>& pi_ = pinfo[j & 1];
@@ -319,9 +371,9 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           pi_.cst[q] = TR ? Lk.cst[part] : T(0);
         }
         pi_.pairRowC = wd.pairRowC; pi_.loneRowC = wd.loneRowC;
-        for (int i = 0; i < 16; ++i) pi_.prt[i] = wd.prt[i] < 0 ? 0 : wd.prt[i];
+        for (int i = 0; i < WMAXB; ++i) pi_.prt[i] = wd.prt[i] < 0 ? 0 : wd.prt[i];
       }
-      if (!TR) solve_eq(wd, d, tb + L::oSe);
+      if (!TR) solve_eq(wd, d, tb + oSe);
       __syncthreads();
     };
     auto leave = [&](int j) {                                  // transposed: the seed = 0 lattice of a patient whose seeded half is complete
@@ -383,7 +435,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
 #pragma unroll
       for (int i = 0; i < WLB; ++i) {
         const bool has = TR ? !((ln >> i) & 1u) : ((ln >> i) & 1u);
-        const T r = tb[L::oLr + i * 64 + ln] * tb[L::oUr + i * 16 + wv] * tb[L::oEr + i * 32 + Sx];
+        const T r = tb[oLr + i * 64 + ln] * tb[oUr + i * 16 + wv] * tb[oEr + i * ES + Sx];
         cL[i] = has ? r : T(0);
       }
       dRv = tab[pi_.droff + (tt | (Sx << WTB))];
@@ -429,12 +481,19 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       auto ext_take = [&](int j, const VecT& nv) {
         if (j < nXc) {
           // column move: rate of column bit WB + j from the source column set (bit j of Tx clear there)
-          const VecT rr = lds_vec(tb + L::oRh + WB * SZLO + j * SZHI + squeeze(Tx, j) * HIS + beta * NC);
+          if constexpr (C::FACT) {
+            const VecT rr = lds_vec(tb + L::oFw + (WB + j) * WIN + beta * NC);
+            const T fx = tb[oFx + (WB + j) * XS + (Tx & ~(1u << j))];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], nv[c], acc[c]);
+            for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c] * fx, nv[c], acc[c]);
+          } else {
+            const VecT rr = lds_vec(tb + L::oRh + WB * SZLO + j * SZHI + squeeze(Tx, j) * HIS + beta * NC);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], nv[c], acc[c]);
+          }
         } else {
           const int i = WTB + (j - nXc);
-          const T r = tb[L::oLr + i * 64 + ln] * tb[L::oUr + i * 16 + wv] * tb[L::oEr + i * 32 + Sx];
+          const T r = tb[oLr + i * 64 + ln] * tb[oUr + i * 16 + wv] * tb[oEr + i * ES + Sx];
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] = fma_m(r, nv[c], acc[c]);
         }
@@ -478,7 +537,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
             r.q[0] = *reinterpret_cast<const u32x4*>(rs + row * QE);
             r.q[1] = *reinterpret_cast<const u32x4*>(rs + WROWS * QE + row * QE);
             const VecT nv = __builtin_bit_cast(VecT, r);
-            const T cw = tb[L::oLr + (WLB + j) * 64 + ln] * tb[L::oUr + (WLB + j) * 16 + wv] * tb[L::oEr + (WLB + j) * 32 + Sx];
+            const T cw = tb[oLr + (WLB + j) * 64 + ln] * tb[oUr + (WLB + j) * 16 + wv] * tb[oEr + (WLB + j) * ES + Sx];
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = fma_m(cw, nv[c], acc[c]);
           }
@@ -495,9 +554,16 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           const int sb = beta ^ (1 << j);
           const int wset = ((TR ? beta : sb) << RB);           // the window setting the rate is taken at (bit RB + j clear)
           const int wsq = ((wset >> (RB + j + 1)) << (RB + j)) | (wset & ((1 << (RB + j)) - 1));
-          const VecT rr = lds_vec(tb + L::oRh + (RB + j) * SZLO + Tx * LOS + wsq);
+          if constexpr (C::FACT) {
+            const VecT rr = lds_vec(tb + L::oFw + (RB + j) * WIN + wset);
+            const T fx = tb[oFx + (RB + j) * XS + Tx];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], Wd[sb][c], acc[c]);
+            for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c] * fx, Wd[sb][c], acc[c]);
+          } else {
+            const VecT rr = lds_vec(tb + L::oRh + (RB + j) * SZLO + Tx * LOS + wsq);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fma_m(rr[c], Wd[sb][c], acc[c]);
+          }
         }
       }
       if (nX > 2) {
@@ -516,7 +582,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       const uint32_t Tblk = (Tx << HB) | (uint32_t)beta;       // column set of the block >> RB
       if (!TR) {
         if (__builtin_amdgcn_ballot_w64((hitT >> RB) == Tblk) != 0ull) {  // (rare: skipped by a scalar branch)
-          const T hv = (hitT >> RB) == Tblk ? tb[L::oSe + hitE] : T(0);
+          const T hv = (hitT >> RB) == Tblk ? tb[oSe + hitE] : T(0);
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] += ((hitT & (uint32_t)(NC - 1)) == (uint32_t)c) ? hv : T(0);
         }
@@ -537,7 +603,16 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       }
       __builtin_amdgcn_sched_barrier(0);
       // the block itself: moves along the RB lowest column bits (only the rates in use are fetched), diagonal
-      const VecT dcv = lds_vec(tb + L::oDC + Tx * HIS + beta * NC);
+      const VecT dcv = lds_vec(tb + oDC + Tx * HIS + beta * NC);
+      T fxr[RB];                                               // FACT: external factors of the RB lowest column bits
+      if constexpr (C::FACT) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) fxr[r] = tb[oFx + r * XS + Tx];
+      }
+      auto blk_rate = [&](int r, int wset, int wsq) -> T {     // rate of column bit r at window setting wset (bit r clear)
+        if constexpr (C::FACT) return tb[L::oFw + r * WIN + wset] * fxr[r];
+        else return tb[L::oRh + r * SZLO + Tx * LOS + wsq];
+      };
       VecT Y;
       if (!TR) {
 #pragma unroll
@@ -549,7 +624,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
               constexpr int dummy = 0; (void)dummy;
               const int wset = (beta << RB) | (c ^ (1 << r));
               const int wsq = ((wset >> (r + 1)) << r) | (wset & ((1 << r) - 1));
-              z = fma_m(tb[L::oRh + r * SZLO + Tx * LOS + wsq], Y[c ^ (1 << r)], z);
+              z = fma_m(blk_rate(r, wset, wsq), Y[c ^ (1 << r)], z);
             }
           Y[c] = z * fast_rcp(dRv + dcv[c]);
         }
@@ -562,7 +637,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
             if (!((c >> r) & 1)) {
               const int wset = (beta << RB) | c;
               const int wsq = ((wset >> (r + 1)) << r) | (wset & ((1 << r) - 1));
-              z = fma_m(tb[L::oRh + r * SZLO + Tx * LOS + wsq], Y[c | (1 << r)], z);
+              z = fma_m(blk_rate(r, wset, wsq), Y[c | (1 << r)], z);
             }
           Y[c] = z * fast_rcp(dRv + dcv[c]);
         }

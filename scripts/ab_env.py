@@ -16,7 +16,15 @@ sys.path.insert(0, %r)
 from metmhn_amd import Engine, synthetic
 P, n, dtype = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 lt, dp, dm = synthetic.random_params(n)
-dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
+shapes = os.environ.get("AB_SHAPES")            # e.g. "14,10;15,9": only paired rows with these (larger, smaller) class sizes
+if shapes:
+    want = {tuple(int(v) for v in s.split(",")) for s in shapes.split(";")}
+    big = np.asarray(synthetic.full_k_cohort(n, 8 * P, seed=2000 + n))
+    kp, km = big[:, 0:2 * n:2].sum(1), big[:, 1:2 * n:2].sum(1)
+    keep = [i for i in range(len(big)) if (max(kp[i], km[i]), min(kp[i], km[i])) in want][:P]
+    dat = big[keep]
+else:
+    dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
 e = Engine(n, dtype=dtype); e.set_cohort(dat)
 for _ in range(2): s = e.cohort_sums(lt, dp, dm)
 e.reset_counters()
@@ -24,7 +32,7 @@ t0 = time.perf_counter()
 for _ in range(5): s = e.cohort_sums(lt, dp, dm)
 dt = (time.perf_counter() - t0) / 5
 c = e.counters()
-print(json.dumps(dict(ms=dt * 1e3, fwd=c["psolve_fwd"]["ms"] / 5, adj=c["psolve_adj"]["ms"] / 5, marg=c["pclass"]["ms"] / 5,
+print(json.dumps(dict(rows=len(dat), ms=dt * 1e3, fwd=c["psolve_fwd"]["ms"] / 5, adj=c["psolve_adj"]["ms"] / 5, marg=c["pclass"]["ms"] / 5,
                       other=c["other_solve"]["ms"] / 5, s0=float(s[0]), g=float(np.abs(s[4:]).sum()))))
 ''' % ROOT
 
@@ -53,5 +61,5 @@ for r in range(rounds):
             print(v, "FAILED", out.stderr[-800:]); continue
         if ref is None:
             ref = d
-        print(f"round {r} {v:40s} {d['ms']:8.2f} ms  fwd {d['fwd']:6.2f} adj {d['adj']:6.2f} marg {d['marg']:6.2f} other {d['other']:5.2f}"
+        print(f"round {r} {v:40s} {d['rows']} rows {d['ms']:8.2f} ms  fwd {d['fwd']:6.2f} adj {d['adj']:6.2f} marg {d['marg']:6.2f} other {d['other']:5.2f}"
               f"  d_lp {abs(d['s0'] - ref['s0']) / abs(ref['s0']):.1e} d_g {abs(d['g'] - ref['g']) / abs(ref['g']):.1e}", flush=True)

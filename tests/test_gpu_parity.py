@@ -1207,6 +1207,52 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
 
 
 
+@pytest.mark.gpu
+def test_window_path_fp32_k25_shapes(monkeypatch):
+    """The fp32 window path (BASELINE configs[4]: k = 25, nine external bits): column-class rates as two factors in LDS
+    (csrc/wsolve.h, WCfg<float>::FACT), tables packed per shape, up to 12 column bits, 18 row bits, 12 paired events.
+    Designed shapes - two patients of one shape in a row (a chain), either class as rows, the extremes of every bound -
+    against oracle/metmhn_fast.c (fp64) at the fp32 bar, (a) all k = 25: the instantiation with the number of external
+    bits known at compile time, (b) mixed k: the generic one; and every row again on the tile kernels (MMHN_WSOLVE=0)."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 25
+    lt, dp, dm = synthetic.random_params(n)
+    r = list(range(n))
+    k25 = [
+        _row(n, r[0:12], r[1:13], 0),                           # (12, 12), eleven pairs
+        _row(n, r[5:17], r[4:16], 2),                           # (12, 12) again: chained behind the first
+        _row(n, r[0:18], r[12:18], 1),                          # (18, 6): eight external row bits, every MT event paired
+        _row(n, r[0:11], r[8:21], 0),                           # MT rows (13, 11), three pairs
+        _row(n, r[0:15], r[15:24], 1),                          # (15, 9), no pair
+        _row(n, r[3:15], r[5:17], 2),                           # (12, 12), ten pairs
+        _row(n, r[0:16], r[10:18], 0),                          # (16, 8)
+    ]
+    mixed = [
+        _row(n, r[0:10], r[10:20], 0),                          # k = 21: (10, 10), no external row bit
+        _row(n, r[0:16], r[16:22], 1),                          # k = 23: (16, 6)
+        _row(n, r[2:14], r[0:12], 2),                           # k = 25: (12, 12)
+        _row(n, r[0:7], r[5:17], 0),                            # k = 20: MT rows (12, 7)
+        _row(n, r[0:19], r[19:24], 0),                          # k = 25, 19 row bits: beyond the window path
+    ]
+    monkeypatch.setenv("MMHN_PSOLVE_MIN", "1")
+    monkeypatch.setenv("MMHN_POISON", "1")
+    for tag, cohort in (("k25", k25), ("mixed", mixed)):
+        dat = np.array(cohort, dtype=np.int8)
+        lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+        for ms in ("1", "0"):
+            monkeypatch.setenv("MMHN_WSOLVE", ms)
+            e = Engine(n, dtype="f32")
+            e.set_cohort(dat)
+            res = e.patient_grads(lt, dp, dm)
+            e.close()
+            assert all(np.isfinite(x).all() for x in res)
+            np.testing.assert_allclose(res[0], lp, rtol=1e-4)
+            for x32, x64, nm in ((res[1], g, "d_theta"), (res[2], a, "d_dp"), (res[3], b, "d_dm")):
+                err, tol = _fp32_report(f"{tag} WSOLVE={ms} {nm}", x32, x64)
+                assert (err <= tol).all(), (tag, ms, nm)
+
+
 def _rccl_worker(rank, world, port, q):
     """One rank of the in-library RCCL test: its own GPU, backend nccl, MMHN_STRICT_COMM=1 (no fallback to torch's
     collective), the golden cohort c0 sharded over the ranks."""
