@@ -636,11 +636,11 @@ struct Engine : EngineBase {
   void launch_grad_rows(const Desc* descs, int nprob, int maxk, const T* A, const T* p, const T* q, T* G, int kind,
                         const DevArr<int2>& chunks, T* dj = nullptr, long long gstride = 0) {
     if (nprob == 0 || chunks.n == 0) return;
-    const int maxhi = std::max(0, std::min(maxk, GR_CHUNK) - 6);     // high-bit accumulators: bits inside a chunk only
-    const size_t lds = ((size_t)WAVES * 192 + WAVES * 32 + (size_t)WAVES * maxhi * 64) * sizeof(T);
+    (void)maxk;
+    const size_t lds = ((size_t)WAVES * 192 + WAVES * 32) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
     hipLaunchKernelGGL((k_grad_rows<T>), dim3((unsigned)chunks.n, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream,
-                       descs, d_par.p, A, p, q, G, kind, maxhi, dj, chunks.p, nprob, gstride);
+                       descs, d_par.p, A, p, q, G, kind, dj, chunks.p, nprob, gstride);
     HIPCHECK(hipGetLastError());
   }
   void zero(T* p, long long count) {

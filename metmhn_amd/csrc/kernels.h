@@ -2654,12 +2654,11 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      const T* __restrict__ A,
                                                      const T* __restrict__ p,
                                                      const T* __restrict__ q, T* G, int kind_arg,
-                                                     int maxhi, T* DJ, const int2* __restrict__ chunks,
+                                                     T* DJ, const int2* __restrict__ chunks,
                                                      int nprob, long long gstride) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][3][64]: rate products over subset bits 0-5, 6-11, 12-17
   T* rowbuf = Tlo + WAVES * 192;                // [WAVES][32]
-  T* hiacc = rowbuf + WAVES * 32;               // [WAVES][maxhi][64]
   __shared__ int lev[32];                       // event of local bit l
   // (problem, subset chunk) work list; kind_arg < 0: the kind rides in bits 24+ of the chunk field and selects the G matrix
   const int prob = chunks[blockIdx.x].x;
@@ -2714,8 +2713,11 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       }
       Tlo[w * 192 + part * 64 + lane] = v;
     }
-    T* ha = hiacc + (long long)w * maxhi * 64;
-    for (int l = 0; l < nhi; ++l) ha[l * 64 + lane] = 0;
+    // per-lane sums over the subsets that have subset bit 6 + l (wave-uniform tests: a scalar branch around one add)
+    constexpr int NHI = GR_CHUNK - 6;
+    T ha[NHI];
+#pragma unroll
+    for (int l = 0; l < NHI; ++l) ha[l] = 0;
     const T* Ab = nullptr;
     if (kind != GK_S) {
       long long o = d.aoff;
@@ -2761,7 +2763,8 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
         for (int l = 18; l < kc; ++l) if ((S0 >> l) & 1) urate *= fvec[lev[l]];
         const T f = live[u] ? urate * Tlo[w * 192 + (s & 63u)] * (a0[u] + a1[u]) : T(0);
         tot += f;
-        for (int l = 0; l < nhi; ++l) if ((S0 >> (klo + l)) & 1) ha[l * 64 + lane] += f;
+#pragma unroll
+        for (int l = 0; l < NHI; ++l) if (l < nhi && ((S0 >> (6 + l)) & 1)) ha[l] += f;
       }
     }
     const T total = wave_sum(tot);
@@ -2769,10 +2772,16 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
       if (drow) { if (kind != GK_E) rb[n] = total; }
       else { rb[i] = total; if (kind == GK_M) rb[n] = total; }
     }
-    for (int l = 0; l < kin; ++l) {
-      const T v = l < klo ? (((lane >> l) & 1) ? tot : T(0)) : ha[(l - klo) * 64 + lane];
-      const T m = wave_sum(v);
+    for (int l = 0; l < klo; ++l) {
+      const T m = wave_sum(((lane >> l) & 1) ? tot : T(0));
       if (lane == 0 && lev[l] != i) rb[lev[l]] = m;
+    }
+#pragma unroll
+    for (int l = 0; l < NHI; ++l) {
+      if (l < nhi) {                                             // (nhi > 0 only with klo = 6)
+        const T m = wave_sum(ha[l]);
+        if (lane == 0 && lev[6 + l] != i) rb[lev[6 + l]] = m;
+      }
     }
     // bits at or above the chunk size are the same for every subset of the chunk
     if (lane == 0)
