@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Timeline of the last evaluation in a rocprofv3 --kernel-trace csv (scripts/eval_only.py): kernel, start offset, duration, gap to
+the previous kernel's end (us).    python scripts/eval_timeline.py <kernel_trace.csv>"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "k_begin_eval" in r["Kernel_Name"]]
+first = starts[-1] if starts else 0
+t0 = int(rows[first]["Start_Timestamp"])
+prev_end = t0
+busy = 0
+for r in rows[first:]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].replace("mmhn::", "").replace("void ", "")
+    name = name[:name.index("(")] if "(" in name else name
+    print(f"{(s - t0) / 1e3:10.1f} us  {(e - s) / 1e3:10.1f} us  gap {(s - prev_end) / 1e3:8.1f}  {name[:70]}")
+    busy += e - s
+    prev_end = max(prev_end, e)
+print(f"span {(prev_end - t0) / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us")
