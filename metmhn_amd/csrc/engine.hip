@@ -544,9 +544,11 @@ struct Engine : EngineBase {
   size_t sweep_lds(int maxk) const { return DESC_PAD + ((size_t)(1 << TB) + 2 * (size_t)std::max(maxk, 1) * 64) * sizeof(T); }
   // joint: a workgroup per table of a problem (three class tables + the rate tables, k_prep) when the launch is short
   // enough for its length to be one workgroup's chain; large cohorts keep one workgroup per problem
-  void prep(const Desc* descs, int nprob, T* tab, bool joint = false) {
+  // (tables of more than 2^13 entries - k = 25 - are also cut into parts of 2^13: grid.y = 4 * parts)
+  void prep(const Desc* descs, int nprob, T* tab, bool joint = false, int maxkc = 0) {
     if (nprob == 0) return;
-    if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    const int parts = maxkc > 13 ? 1 << (maxkc - 13) : 1;
+    if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4 * parts), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
   }
@@ -1231,7 +1233,7 @@ struct Engine : EngineBase {
       DJ.p = GJ.p + up4(3 * gjs);
       Abuf.p = DJ.p + up4(3ll * nJ * N);
       if (grad && nJ && !(head_done && &b == &batches.front())) zero(zarena.p, zarena_elems(nJ, b.asize, N));
-      prep(b.d_dJ.p, nJ, tabJ.p, true);                    // (first: the head of the critical chain)
+      prep(b.d_dJ.p, nJ, tabJ.p, true, b.maxkcJ);                    // (first: the head of the critical chain)
       // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
       // run on a side stream from here on, next to the joint forward solve (whose launch is issued first - it is the
       // critical chain); the assembly waits for them

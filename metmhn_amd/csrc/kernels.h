@@ -105,7 +105,9 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
   T* out = tab + d.toff;
   // SPLIT (gridDim.y == 4): the three class tables and the rate tables of a problem are independent - a workgroup
   // each, so the kernel at the head of every evaluation is one table long (small cohorts); else all in this one
-  const int job = SPLIT ? (int)blockIdx.y : -1;
+  const int job = SPLIT ? (int)(blockIdx.y & 3u) : -1;
+  const int part = SPLIT ? (int)(blockIdx.y >> 2) : 0, nparts = SPLIT ? (int)(gridDim.y >> 2) : 1;   // a long table: S dealt over parts
+  if (job == 3 && part > 0) return;
   if (job < 0 || job == 3) {
   for (int e = tid; e < k * k; e += BLOCK) {
     const int b = e / k, bb = e % k;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     const uint32_t cm = c == 0 ? d.maskP : c == 1 ? d.maskM : d.pairP;
     const int kc = __popc(cm);
     if (job >= 0 && c != job) { o += 1ll << kc; continue; }
+    if ((long long)part * BLOCK >= (1ll << kc)) return;        // (uniform: nothing of this table falls to this part)
     __syncthreads();
     // th[i][l] = theta[i][event of the l-th class bit]
     for (int e = tid; e < N * kc; e += BLOCK) {
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
       }
       __syncthreads();
     }
-    for (long long S = tid; S < (1ll << kc); S += BLOCK) {
+    for (long long S = tid + (long long)part * BLOCK; S < (1ll << kc); S += (long long)BLOCK * nparts) {
       const int s0 = (int)(S & 63), s1 = (int)((S >> 6) & 63), s2 = (int)(S >> 12);
       T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
       if (split) { T m = rsplit[N * 192 + s0]; if (np6 > 1) m *= rsplit[N * 192 + 64 + s1]; if (np6 > 2) m *= rsplit[N * 192 + 128 + s2]; obs *= m; }
