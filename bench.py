@@ -469,6 +469,27 @@ def main():
                 out["check"] = {"against": "oracle/metmhn_fast.c on the host (fp64), first rows of the bench cohort", "errors": errs,
                                 "tolerance": 1e-6 if a.dtype == "f64" else 1e-2}
             note("optimised CPU baseline + cross-check done")
+        if world == 1 and not a.no_extras and a.workload == "full-k" and a.config == 2 and a.n == 20:
+            # ---- BASELINE configs[4] shape (n = k = 25, fp32, 128 MiB vectors) on a bounded sample: one resident batch of
+            # 768 patients (three per CU), in a child process after this one's engines are gone - a reported figure beside the
+            # headline, not part of `value`
+            try:
+                ro.invalidate()
+                import gc
+                gc.collect()
+                cmd = [sys.executable, os.path.abspath(__file__), "--n", "25", "--dtype", "f32", "--patients", "768", "--steps", "2",
+                       "--warmup", "1", "--no-cpu", "--no-extras"]
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = json.loads(res.stdout.strip().splitlines()[-1])
+                out["config4_batch"] = {
+                    "workload": "synthetic full-k cohort, n=25 events, 768 paired patients (one workspace batch of BASELINE configs[4]), "
+                                "2^25-state vectors, f32", "patients": 768, "ms_per_step": line["ms_per_step"],
+                    "ms_per_patient": line["ms_per_step"] / 768.0, "dtype": "f32",
+                    "roofline": {k: line["roofline"].get(k) for k in ("kernel", "frac", "achieved", "avg_launch_ms", "alg_bytes_per_launch")},
+                    "roofline_marginals": {k: line.get("roofline_marginals", {}).get(k) for k in ("kernel", "frac", "avg_launch_ms")}}
+            except Exception as exc:
+                out["config4_batch"] = {"error": repr(exc)}
+            note("configs[4]-shaped batch done")
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -55,8 +55,11 @@ template <typename T> struct WCfg;
 //       setting] (one more multiply per fetched rate vector, 8 KB instead of kC * 2^(kC-1) entries): what lets twelve
 //       column bits fit.  fp64 keeps the full tables (nine column bits cover every k = 20 shape).
 // ON: the engine uses the window path for this dtype.
+#ifndef MMHN_WHB
+#define MMHN_WHB 2    // build switch (experiments): log2 of the blocks of a window, fp64
+#endif
 template <> struct WCfg<double> {
-  static constexpr int RB = 2, HB = 2, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = 5;
+  static constexpr int RB = 2, HB = MMHN_WHB, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = 7 - MMHN_WHB;
   static constexpr bool FACT = false, ON = true;
 };
 #ifndef MMHN_WF32
