@@ -348,7 +348,7 @@ def main():
             return o
 
         T = "double" if a.dtype == "f64" else "float"
-        wsolve = os.environ.get("MMHN_WSOLVE", "1") != "0" and a.dtype == "f64"
+        wsolve = os.environ.get("MMHN_WSOLVE", "1") != "0"
         ksolve = "k_wsolve" if wsolve else "k_psolve2"
         rf_fwd = kern("psolve_fwd", f"{ksolve}<{T},false> (forward substitution solve of the joint problems"
                       + (", window layout: a chain of patients per workgroup)" if wsolve else ", one workgroup per patient)"),
