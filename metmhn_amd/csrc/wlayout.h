@@ -54,20 +54,21 @@ template <typename T> struct WCfg;
 // FACT: the rates of the column-class events are kept as two factors, [event][window setting] x [event][external column
 //       setting] (one more multiply per fetched rate vector, 8 KB instead of kC * 2^(kC-1) entries): what lets twelve
 //       column bits fit.  fp64 keeps the full tables (nine column bits cover every k = 20 shape).
+// REV: order in which a step requests its external blocks (wsolve.h).
 // ON: the engine uses the window path for this dtype.
 #ifndef MMHN_WHB
 #define MMHN_WHB 2    // build switch (experiments): log2 of the blocks of a window, fp64
 #endif
 template <> struct WCfg<double> {
   static constexpr int RB = 2, HB = MMHN_WHB, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = 7 - MMHN_WHB;
-  static constexpr bool FACT = false, ON = true;
+  static constexpr bool FACT = false, REV = true, ON = true;
 };
 #ifndef MMHN_WF32
 #define MMHN_WF32 1   // build switch: 0 = fp32 cohorts on the tile kernels (k_psolve2 / k_pclass) only
 #endif
 template <> struct WCfg<float> {
   static constexpr int RB = 3, HB = 2, KC = 12, KR = 18, KE = 12, PAD = 4, NXT = 9;
-  static constexpr bool FACT = true, ON = MMHN_WF32 != 0;
+  static constexpr bool FACT = true, REV = false, ON = MMHN_WF32 != 0;
 };
 
 // static description of one joint problem on the window path (host-built, set_cohort)

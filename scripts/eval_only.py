@@ -18,6 +18,12 @@ else:
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     lt, dp, dm = synthetic.random_params(n)
     dat = synthetic.full_k_cohort(n, P, seed=2000 + n)
+    if os.environ.get("AB_SHAPES"):                           # e.g. "12,12;13,11": only rows with these (larger, smaller) class sizes
+        want = {tuple(int(v) for v in s.split(",")) for s in os.environ["AB_SHAPES"].split(";")}
+        big = np.asarray(synthetic.full_k_cohort(n, 8 * P, seed=2000 + n))
+        kp, km = big[:, 0:2 * n:2].sum(1), big[:, 1:2 * n:2].sum(1)
+        dat = big[[i for i in range(len(big)) if (max(kp[i], km[i]), min(kp[i], km[i])) in want][:P]]
+        os.environ.setdefault("MMHN_PSOLVE_MIN", "1")
 e = Engine(n, dtype=sys.argv[3] if len(sys.argv) > 3 else "f64")
 e.set_cohort(dat)
 for _ in range(2):
