@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     const Desc& d0 = descs[w0.prob];
     const int k = sgpr(d0.k), kR = sgpr(w0.kR), kC = sgpr(w0.kC), nXc = sgpr(w0.nXc), nXr = sgpr(w0.nXr);
     const int nX = NXT >= 0 ? NXT : nXc + nXr;
-    constexpr bool DEEP = NXT >= 7;
+    constexpr bool DEEP = NXT >= 7;                            // (at five external bits - k = 20 - measured slower: 13.4 against 13.1 ms)
     // table offsets: constants with the full tables, per shape with the factored ones
     const WOff wo = L::offsets(kR, kC);
     const int oFx = C::FACT ? sgpr(wo.oFx) : L::oFx, XS = C::FACT ? sgpr(wo.XS) : (1 << L::NXCM);
@@ -548,14 +548,14 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           }
         }
       }
-      // DEEP (seven or more external bits, known at compile time - k = 25): the pairs of external blocks are requested one
+      // DEEP (seven or more external bits, known at compile time - k = 25: 9): the pairs of external blocks are requested one
       // phase ahead of their use all the way down the step, instead of request-and-wait pairs at its end
       if constexpr (DEEP) {
         __builtin_amdgcn_sched_barrier(0);
         ext_take(sb(2), ev0);
         ext_take(sb(3), ev1);
         ev0 = ld_row(ext_off(sb(4)), boff);
-        ev1 = ld_row(ext_off(sb(5)), boff);
+        if (nX > 5) ev1 = ld_row(ext_off(sb(5)), boff);
       }
       __builtin_amdgcn_sched_barrier(0);
       STAMP(2);
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       if constexpr (DEEP) {
         __builtin_amdgcn_sched_barrier(0);
         ext_take(sb(4), ev0);
-        ext_take(sb(5), ev1);
-        ev0 = ld_row(ext_off(sb(6)), boff);
+        if (nX > 5) ext_take(sb(5), ev1);
+        if (nX > 6) ev0 = ld_row(ext_off(sb(6)), boff);
         if (nX > 7) ev1 = ld_row(ext_off(sb(7)), boff);
       } else if (nX > 2) {
         ext_take(sb(2), ev0);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DEEP) {
-        ext_take(sb(6), ev0);
+        if (nX > 6) ext_take(sb(6), ev0);
         if (nX > 7) ext_take(sb(7), ev1);
         for (int j0 = 8; j0 < nX; j0 += 2) {
           ev0 = ld_row(ext_off(sb(j0)), boff);
