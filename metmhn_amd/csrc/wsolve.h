@@ -239,6 +239,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     const Desc& d0 = descs[w0.prob];
     const int k = sgpr(d0.k), kR = sgpr(w0.kR), kC = sgpr(w0.kC), nXc = sgpr(w0.nXc), nXr = sgpr(w0.nXr);
     const int nX = NXT >= 0 ? NXT : nXc + nXr;
+    constexpr bool EV2 = TR && NXT == 5;
     constexpr bool DEEP = NXT >= 7;                            // (at five external bits - k = 20 - measured slower: 13.4 against 13.1 ms)
     // table offsets: constants with the full tables, per shape with the factored ones
     const WOff wo = L::offsets(kR, kC);
@@ -528,6 +529,10 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         ev0 = ld_row(ext_off(sb(2)), boff);
         if (nX > 3) ev1 = ld_row(ext_off(sb(3)), boff);
       }
+      // EV2 (transposed, five external bits - every k = 20 cohort): the fifth request goes out with the second pair into a
+      // register set of its own instead of request-and-wait at the end (adjoint 14.1 -> 13.2 ms; forward 13.1 -> 13.6: off there)
+      VecT ev2;
+      if constexpr (EV2) ev2 = ld_row(ext_off(sb(4)), boff);
       __builtin_amdgcn_sched_barrier(0);
       STAMP(1);
       // wave moves: the block the neighbour wave published one step ago
@@ -589,6 +594,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       } else if (nX > 2) {
         ext_take(sb(2), ev0);
         if (nX > 3) ext_take(sb(3), ev1);
+        if constexpr (EV2) ext_take(sb(4), ev2);
+        else
         for (int j0 = 4; j0 < nX; j0 += 2) {                   // (spaces of more than 20 bits)
           ev0 = ld_row(ext_off(sb(j0)), boff);
           if (j0 + 1 < nX) ev1 = ld_row(ext_off(sb(j0 + 1)), boff);
