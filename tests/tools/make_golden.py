@@ -5,7 +5,8 @@ Runs ONLY in the build container (needs /root/reference, which never travels):
 
     PYTHONDONTWRITEBYTECODE=1 \
     PYTHONPATH=tests/tools/jax_standin:/root/reference \
-    python tests/tools/make_golden.py
+    python tests/tools/make_golden.py            # primitives, vanilla, patients, cohorts
+    python tests/tools/make_golden.py large      # large.npz: three paired rows with k = 16 - 18 (minutes per row)
 
 The reference (cbg-ethz/metMHN @ 2024_08_07) is pure Python on JAX; jax is not
 installed here, so its source is executed eagerly under the NumPy stand-in in
@@ -278,10 +279,41 @@ def cohorts():
     print("cohorts: 4")
 
 
+def large():
+    """Three paired rows in the regime the window kernels run in (>= 10 bits in one class, >= 4 in the other):
+    n = 12, (kP, kM) = (10, 5), (11, 6), (6, 11), orders 0 / 1 / 2 -> k = 16, 18, 18, through the reference's
+    _g_coupled_0/1/2 (likelihood.py:623-731) as regularized_optimization.py:227-254 calls them."""
+    import time
+    rng = np.random.default_rng(1618)
+    n = 12
+    lt, dp, dm = rand_params(rng, n, 0.6)
+    rows = []
+    for (kP, kM), order in (((10, 5), 0), ((11, 6), 1), ((6, 11), 2)):
+        r = np.zeros(2 * n + 3, dtype=np.int8)
+        r[2 * rng.choice(n, kP, replace=False)] = 1
+        r[2 * rng.choice(n, kM, replace=False) + 1] = 1
+        r[2 * n], r[2 * n + 1], r[2 * n + 2] = 1, order, 3
+        rows.append(r)
+    dat = np.array(rows, dtype=np.int8)
+    out = {"log_theta": lt, "log_d_p": dp, "log_d_m": dm, "dat": dat}
+    lps, gths, gdps, gdms = [], [], [], []
+    for r in dat:
+        t0 = time.time()
+        s, g, a, b = ro.score_and_grad(J(lt), J(dp), J(dm), J(r.reshape(1, -1)), 0.5)
+        lps.append(float(np.asarray(s).reshape(-1)[0]))
+        gths.append(A(g)); gdps.append(A(a)); gdms.append(A(b))
+        print("large: k =", int(r[:2 * n + 1].sum()), "lp", lps[-1], f"{time.time() - t0:.0f} s", flush=True)
+    out["lp"], out["d_th"], out["d_dp"], out["d_dm"] = np.array(lps), np.array(gths), np.array(gdps), np.array(gdms)
+    np.savez_compressed(os.path.join(OUT, "large.npz"), **out)
+
+
 if __name__ == "__main__":
     if not os.path.isdir("/root/reference/metmhn"):
         sys.exit("needs /root/reference (build container only)")
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        large()
+        sys.exit(0)
     primitives()
     vanilla()
     patients()
