@@ -29,6 +29,7 @@
 
 #include "../../include/metmhn_amd.h"
 #include "kernels.h"
+#include "tsolve.h"
 #include "small.h"
 #include "wsolve.h"
 #include "wclass.h"
@@ -80,6 +81,18 @@ struct DevArr {
   }
 };
 
+// work list of one cooperative solve launch (tsolve.h: k_csolve), host + device copy
+struct CList {
+  std::vector<CItem> items;
+  std::vector<int> deps;
+  DevArr<CItem> d_items;
+  DevArr<int> d_deps;
+  int maxk = 0;
+  int nlevels = 0;               // levels of the deepest problem (1: no tile waits for another one)
+  void clear() { items.clear(); deps.clear(); maxk = 0; nlevels = 0; }
+};
+enum Route : uint8_t { RT_W = 0, RT_P = 1, RT_T = 2 };
+
 // static (per cohort) description of one batch of patients
 struct Batch {
   std::vector<PatRec> pats;
@@ -100,38 +113,57 @@ struct Batch {
   DevArr<int2> d_mapX;
   DevArr<int2> d_grc[4];         // k_grad_rows work lists per kind (GK_P, GK_M, GK_E: joint problems, GK_S: single)
   DevArr<int2> d_grcJ;           // the three joint kinds in one list (kind in bits 24+ of .y): one launch
-  // small-space path (small.h): patients by size class of their largest single-tumour space; sp_ok: every one fits a tile
-  // [0]: patients that are their own single-tumour problem (dat types 0-2: nothing of the joint path feeds them),
-  // [1]: paired patients (their single-tumour problems are marginals of the joint forward solution)
-  // [0]: patients that are their own problem, [1]: paired rows, [2]: the paired rows with both marginal problems whose
-  // class has a side-by-side kernel (small.h PAIR) - taken out of [1]
+  // small-space path (small.h): patients whose single-tumour spaces all fit a tile, by size class of the largest one
+  // [0]: patients that are their own problem (dat types 0-2: nothing of the joint path feeds them), [1]: paired rows (their
+  // single-tumour problems are marginals of the joint forward solution), [2]: the paired rows with both marginal problems
+  // whose class has a side-by-side kernel (small.h PAIR) - taken out of [1]
   std::vector<int> sp_list[3][SP_NCLASS];
   DevArr<int> d_sp_list[3][SP_NCLASS];
-  bool sp_ok = false;
+  bool has_small = false;        // some patient takes the small-space path
   int mk1p = 9;                  // bits the 256-thread class of the paired rows is sized for (spatient_class_maxk(1) or up to 10)
-  std::vector<int> paired;       // patients with a joint problem (k_gather_marg runs over these only)
+  // ... the other patients (a single-tumour space of more than a tile; MMHN_SMALL=0 / the Jacobi solver: every patient)
+  // take the staged kernels over these lists
+  std::vector<int> gpats, gpaired, gprobs;   // staged patients; those of them with a joint problem; their single-tumour problems
+  DevArr<int> d_gpats, d_gpaired, d_gprobs;
+  std::vector<int2> mapG, lmapG;             // tiles of the staged problems (map order / by level)
+  std::vector<int> lofG;
+  DevArr<int2> d_mapG, d_lmapG;
+  DevArr<int2> d_grcG;                       // k_grad_rows work list (GK_S) of the staged problems
+  int maxkG = 0;
+  long long tilesG_vec = 0;                  // elements of the staged problems' vectors (Jacobi pricing)
+  bool g_kind2 = false;                      // a staged patient is an MT-only row
+  std::vector<int> paired;       // patients with a joint problem
   DevArr<int> d_paired;
-  std::vector<int> olist;        // joint problems that stay on the tile kernels
+  // ---- per-problem dispatch of the joint solves (round 5).  Every joint problem takes ONE of three routes:
+  //   RT_W  window layout, a chain of patients per workgroup (wsolve.h) - when the batch has enough window-shaped problems
+  //   RT_P  one workgroup per patient walking its tiles (k_psolve2)   - multi-tile problems, when there are enough of them
+  //   RT_T  the tiles of all remaining problems in ONE cooperative launch (tsolve.h: k_csolve) - several workgroups per patient
+  std::vector<uint8_t> route;
+  std::vector<int> olist;        // the RT_P problems
   DevArr<int> d_olist;
-  // window path (wsolve.h): the same dispatch, 15 / 16 index bits on the chip
-  bool wpath = false;
+  bool wpath = false;            // the batch has RT_W problems
   bool wdirect = false;          // the consumers read the window layout in place (no conversion to index order)
   std::vector<WDesc> wd;         // sorted by shape; the state vectors of consecutive entries lie back to back
   DevArr<WDesc> d_wd;
   int wnx = -1;                  // external bits of every window problem of the batch, -1: they differ
   std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
   DevArr<WChain> d_wchains;
-  // the few problems the window path leaves over: tile-level solver (one patient walking its tiles alone takes ~2 ms)
-  std::vector<int2> lmapO;
-  std::vector<int> lofO;
-  DevArr<int2> d_lmapO;
-  int maxkO = 0;
-  bool all_multi = false;        // every joint problem is a multi-tile space with at most TB paired events
-  int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the joint problems
-  std::vector<int> ptoff;
+  long long offT = 0;            // the RT_T problems' vectors start here (the tile solver skips their dead tiles: kept zero)
+  CList clJ[2], clG[2];          // cooperative work lists, forward / transposed: RT_T joint tiles; staged single-tumour tiles
+  std::vector<int2> lmapT;       // the RT_T tiles by level (MMHN_COOP=0: one launch per level)
+  std::vector<int> lofT;
+  DevArr<int2> d_lmapT;
+  int maxkT = 0, maxkP = 0;      // largest RT_T / RT_P problem
+  int max_dl = 0;                // largest (2^#P bits in a tile + 2^#M bits in a tile) over the RT_P problems
+  std::vector<int> ptoff;        // live (seeded) tiles of the RT_P problems in index order (k_psolve2)
   std::vector<uint32_t> ptiles;
   DevArr<int> d_ptoff;
   DevArr<uint32_t> d_ptiles;
+  double seeded_bytes_P = 0;     // bytes of the RT_P solutions (written once per solve)
+  // class marginals of the problems in index order: work items of k_pclass (problem, class pass or eq block, range of its
+  // outer loop) - a large problem is several workgroups
+  std::vector<int4> pcl;
+  DevArr<int4> d_pcl;
   DevArr<PatRec> d_pats;
   DevArr<Desc> d_dJ, d_dS;
   DevArr<int2> d_mapJ, d_mapS, d_lmapJ, d_lmapS;
@@ -179,6 +211,77 @@ static inline long long a_size(const Desc& d) {
 static void add_tiles(std::vector<int2>& map, int prob, int k) {
   const int tiles = k > TB ? 1 << (k - TB) : 1;
   for (int t = 0; t < tiles; ++t) map.push_back(make_int2(prob, t));
+}
+
+// the tiles a tile's step A reads (tsolve.h: tsolve_tile, same conditions): moves whose bits reach beyond the tile
+static void tile_deps(const Desc& d, uint32_t H, bool tr, std::vector<uint32_t>& out) {
+  out.clear();
+  const int k = d.k, t = k < TB ? k : TB;
+  const bool joint = d.mode == JOINT;
+  for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
+    const bool is_pair = joint && ((d.pairP >> b) & 1u);
+    for (int kind = 0; kind < 2; ++kind) {
+      if (kind == 1 && !is_pair) continue;
+      const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
+      const uint32_t mh = mv >> t;
+      if (mh == 0) continue;
+      if (tr ? (H & mh) != 0 : (H & mh) != mh) continue;
+      const uint32_t Hn = H ^ mh;
+      if (std::find(out.begin(), out.end(), Hn) == out.end()) out.push_back(Hn);
+    }
+  }
+}
+
+// Work list of a cooperative solve over the tiles `map` (dead tiles of joint spaces dropped when `prune`): a topological
+// order of the (transposed) system in which the deepest problems start first - key = levels a tile still has in front of
+// it, counted from the END of its problem, so that every problem finishes in the last rounds (longest remaining path first).
+static void build_clist(const std::vector<int2>& map, const std::vector<Desc>& descs, bool prune, bool tr, CList& cl) {
+  cl.clear();
+  struct Ent { int prob; uint32_t H; int key; int k; };
+  std::vector<Ent> ents;
+  ents.reserve(map.size());
+  std::vector<int> maxlev(descs.size(), 0);
+  for (const int2& m : map) {
+    if (prune && dead_tile(descs[m.x], (uint32_t)m.y)) continue;
+    maxlev[m.x] = std::max(maxlev[m.x], popc((uint32_t)m.y));
+    ents.push_back(Ent{m.x, (uint32_t)m.y, 0, descs[m.x].k});
+  }
+  if (ents.empty()) return;
+  for (Ent& e : ents) {
+    const int lev = popc(e.H);
+    e.key = tr ? -lev : lev - maxlev[e.prob];
+    cl.maxk = std::max(cl.maxk, e.k);
+    cl.nlevels = std::max(cl.nlevels, maxlev[e.prob] + 1);
+  }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.k > b.k; });
+  // position of every live tile in the list
+  std::vector<long long> toff(descs.size() + 1, 0);
+  std::vector<char> used(descs.size(), 0);
+  for (const Ent& e : ents) used[e.prob] = 1;
+  for (size_t p = 0; p < descs.size(); ++p) toff[p + 1] = toff[p] + (used[p] ? (descs[p].k > TB ? 1ll << (descs[p].k - TB) : 1) : 0);
+  std::vector<int> pos((size_t)toff.back(), -1);
+  for (size_t i = 0; i < ents.size(); ++i) pos[(size_t)(toff[ents[i].prob] + ents[i].H)] = (int)i;
+  cl.items.resize(ents.size());
+  std::vector<uint32_t> nb;
+  for (size_t i = 0; i < ents.size(); ++i) {
+    const Ent& e = ents[i];
+    tile_deps(descs[e.prob], e.H, tr, nb);
+    CItem it{e.prob, e.H, (int)cl.deps.size(), 0};
+    for (uint32_t Hn : nb) {
+      const int j = pos[(size_t)(toff[e.prob] + Hn)];
+      if (j < 0) continue;                                   // a dead tile: zeros, written by nobody
+      if (j >= (int)i) throw Fail{"cooperative solve: the work list is not a topological order"};
+      cl.deps.push_back(j);
+      ++it.ndep;
+    }
+    if (it.ndep > 63) throw Fail{"cooperative solve: more than 63 dependencies of one tile"};
+    cl.items[i] = it;
+  }
+  if (cl.deps.empty()) cl.deps.push_back(0);
+  cl.d_items.alloc(cl.items.size());
+  cl.d_deps.alloc(cl.deps.size());
+  HIPCHECK(hipMemcpy(cl.d_items.p, cl.items.data(), cl.items.size() * sizeof(CItem), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(cl.d_deps.p, cl.deps.data(), cl.deps.size() * sizeof(int), hipMemcpyHostToDevice));
 }
 
 struct EngineBase {
@@ -384,8 +487,19 @@ struct Engine : EngineBase {
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int prep_split_max = 2048;    // MMHN_PREP_SPLIT: problems up to which k_prep / k_pclass run a workgroup per table / class pass
   bool pair_small = true;       // MMHN_PAIR_SMALL=0: the two marginal problems of a paired row one after the other
-  int psolve_version = 2;       // MMHN_PSOLVE_V=1: the round-1 per-patient solve kernel (k_psolve) also for all-seeded-tile launches
-  int psolve_min = 384;         // joint problems in a batch from which one-workgroup-per-patient solves are used (MMHN_PSOLVE_MIN)
+  int psolve_min = 384;         // multi-tile joint problems (outside the window route) in a batch from which they take one workgroup
+                                // per patient (k_psolve2) instead of the cooperative tile launch (MMHN_PSOLVE_MIN)
+  int wsolve_min = 128;         // window-shaped joint problems in a batch from which they take the window route (MMHN_WSOLVE_MIN;
+                                // follows MMHN_PSOLVE_MIN when only that one is set)
+  bool coop = true;             // MMHN_COOP=0: tile solves as one launch per level (k_tsolve) instead of one cooperative launch
+  // cooperative launches (tsolve.h): queue heads + abort word, the flags of the tiles (value = epoch of the launch that
+  // finished the tile), the pinned host copy of the abort word
+  DevArr<CoopCtl> coop_ctl;
+  DevArr<unsigned> coop_flags;
+  unsigned coop_epoch = 0;
+  int coop_slot = 0;
+  unsigned* h_abort = nullptr;
+  unsigned* h_abort_dev = nullptr;
   int wsolve_chain = 1;         // MMHN_WSOLVE_CHAIN=0: every window problem its own chain (the pipeline drains between patients)
   int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
   int wsolve_mode = 1;          // joint solves of per-patient batches in the window layout (wsolve.h); MMHN_WSOLVE=0: the tile
@@ -430,9 +544,10 @@ struct Engine : EngineBase {
       HIPCHECK(hipMemcpy(d_lvl.p, lvl.data(), lvl.size() * sizeof(int), hipMemcpyHostToDevice));
       const char* sv = std::getenv("MMHN_SOLVER");
       use_jacobi = sv && std::string(sv) == "jacobi";
-      if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) psolve_min = std::atoi(pm);
+      if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) { psolve_min = std::atoi(pm); wsolve_min = psolve_min; }
+      if (const char* pm = std::getenv("MMHN_WSOLVE_MIN")) wsolve_min = std::atoi(pm);
+      if (const char* pm = std::getenv("MMHN_COOP")) coop = std::atoi(pm) != 0;
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
-      if (const char* pv = std::getenv("MMHN_PSOLVE_V")) psolve_version = std::atoi(pv);
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PAIR_SMALL")) pair_small = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_ZEROCOPY")) zero_copy = std::atoi(sp) != 0;
@@ -452,10 +567,15 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_psolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    coop_ctl.alloc(1);
+    HIPCHECK(hipMemset(coop_ctl.p, 0, sizeof(CoopCtl)));
+    HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abort), 64, hipHostMallocDefault));
+    HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_abort_dev), h_abort, 0));
+    *h_abort = 0u;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int i = 0; i < 2; ++i) {
@@ -498,6 +618,7 @@ struct Engine : EngineBase {
     }
     if (h_par) (void)hipHostFree(h_par);
     if (h_abi) (void)hipHostFree(h_abi);
+    if (h_abort) (void)hipHostFree(h_abort);
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -672,33 +793,23 @@ struct Engine : EngineBase {
     HIPCHECK(hipEventRecord(e1, stream));
   }
 
-  // one list of problems with its tile maps
+  // one list of problems with its tile maps (cl: its cooperative work lists, forward / transposed, or nullptr)
   struct PList {
     const Desc* d; const int2* map; int ntiles; int maxk; long long vec;
     const int2* lmap; const std::vector<int>* lof; const T* tab;
+    const CList* cl = nullptr;
   };
 
-  // joint solves with many patients in flight: one workgroup per patient, single launch (k_psolve)
-  size_t psolve_lds(int maxk) const {
-    return DESC_PAD + ((size_t)(1 << TB) + 2 + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (sizeof(uint16_t) << TB);
-  }
-  // entries for the per-tile dP / dM slices: whatever is left of half a CU's LDS (two workgroups per CU), at most PS_DL
-  int psolve_dl_cap(int maxk) const {
-    const long long spare = (80 * 1024 - 64) - (long long)psolve_lds(maxk);
-    return (int)std::max<long long>(0, std::min<long long>(PS_DL, spare / (long long)sizeof(T)));
-  }
-  // k_psolve2 (all-seeded-tile launches): no popcount permutation of the tile in LDS
+  // k_psolve2 (one workgroup per patient, all-seeded-tile launches)
   size_t psolve2_lds(int maxk) const {
     return DESC_PAD + ((size_t)(1 << TB) + (size_t)((1 << TB) / TSB) + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (size_t)TSB * sizeof(uint16_t);
   }
+  // the joint solves of a batch, every problem on its route (Batch::route)
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();
     if (nJ == 0) return;
-    const int mk = std::max(b.maxkJ, 1);
-    int nold = nJ;                                              // problems the tile kernels take
-    const int* plist = nullptr;
     if (b.wpath) {
-      // window path: the solution is written once (seeded half)
+      // window route: the solution is written once (seeded half)
       const int nW = (int)b.wd.size();
       double bytes = 0;
       for (const WDesc& w : b.wd) bytes += 0.5 * (double)(1ll << b.dJ[w.prob].k) * sizeof(T);
@@ -719,19 +830,10 @@ struct Engine : EngineBase {
         hipLaunchKernelGGL((k_wconvert<T>), dim3(nW, 32), dim3(WROWS), 0, stream, b.d_dJ.p, b.d_wd.p, yw, y);
         HIPCHECK(hipGetLastError());
       }
-      nold = (int)b.olist.size();
-      plist = b.d_olist.p;
-      if (nold == 0) return;
-      if (!b.lmapO.empty()) {
-        // a handful of left-over problems: tile by tile, level by level (parallel over their tiles); the solver skips dead
-        // tiles, which its consumers read: cleared first
-        for (int pj : b.olist) zero(y + b.dJ[pj].off, 1ll << b.dJ[pj].k);
-        const PList LO{b.d_dJ.p, nullptr, (int)b.lmapO.size(), b.maxkO, 0, b.d_lmapO.p, &b.lofO, tabJ.p};
-        solve(tr, LO, y, nullptr, nullptr, rhs_mode, nullptr);
-        return;
-      }
     }
-    if (b.all_multi && psolve_version == 2) {
+    if (!b.olist.empty()) {
+      // one workgroup per patient (multi-tile problems, many of them)
+      const int mk = std::max(b.maxkP, 1);
       const long long spare = (80 * 1024 - 64) - (long long)psolve2_lds(mk);
       const int dl_cap = (int)std::max<long long>(0, std::min<long long>(PS_DL2, spare / (long long)sizeof(T)));
 #ifdef MMHN_ABL_PACK
@@ -741,32 +843,24 @@ struct Engine : EngineBase {
 #endif
       const double bytes = (double)b.ptiles.size() * (double)(1 << TB) * sizeof(T);
       const bool dlok = b.max_dl <= dl_cap;       // every patient's dP / dM tile slices fit the dl area: branch-free instantiation
+      const int nold = (int)b.olist.size();
       timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-#define PS2_ARGS dim3(nold), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap, plist
+#define PS2_ARGS dim3(nold), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap, b.d_olist.p
         if (tr) { if (dlok) hipLaunchKernelGGL((k_psolve2<T, true, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, true, false>), PS2_ARGS); }
         else { if (dlok) hipLaunchKernelGGL((k_psolve2<T, false, true>), PS2_ARGS); else hipLaunchKernelGGL((k_psolve2<T, false, false>), PS2_ARGS); }
 #undef PS2_ARGS
       });
-      return;
     }
-    const int dl_cap = psolve_dl_cap(mk);
-    const size_t lds = psolve_lds(mk) + (size_t)dl_cap * sizeof(T);
-    const double bytes = (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);   // solution written once
-    timed(tr ? MMHN_K_PSOLVE_ADJ : MMHN_K_PSOLVE_FWD, bytes, [&]() {
-#define PS_ARGS dim3(nold), dim3(TSB), lds, stream, b.d_dJ.p, b.d_ptoff.p, b.d_ptiles.p, d_par.p, y, rhs_mode, d_perm.p, mk, tabJ.p, links.p, qS.p, dl_cap, plist
-      if (b.all_multi) {
-        if (tr) hipLaunchKernelGGL((k_psolve<T, true, true>), PS_ARGS);
-        else hipLaunchKernelGGL((k_psolve<T, false, true>), PS_ARGS);
-      } else {
-        if (tr) hipLaunchKernelGGL((k_psolve<T, true, false>), PS_ARGS);
-        else hipLaunchKernelGGL((k_psolve<T, false, false>), PS_ARGS);
-      }
-#undef PS_ARGS
-    });
+    if (!b.lmapT.empty()) {
+      // everything else: all tiles in one cooperative launch (several workgroups per patient)
+      const PList LT{b.d_dJ.p, nullptr, (int)b.lmapT.size(), b.maxkT, 0, b.d_lmapT.p, &b.lofT, tabJ.p, b.clJ};
+      solve(tr, LT, y, nullptr, nullptr, rhs_mode, nullptr);
+    }
   }
 
   // (D - Q)^-1 rhs (tr: transposed) on every problem of a list.
-  //   default: tile-level substitution (k_tsolve), one launch per level of tile-index popcount;
+  //   default: tile-level substitution, ONE cooperative launch over the list's work list (k_csolve); a list of one level,
+  //   lists without a work list (API calls) and MMHN_COOP=0: one launch per level of tile-index popcount (k_tsolve);
   //   MMHN_SOLVER=jacobi: k+1 in-place fused Jacobi sweeps from zero (the reference's iteration).
   void solve(bool tr, const PList& L, T* y, const T* lidg, const T* rhs, int rhs_mode, const T* scal) {
     if (L.ntiles == 0) return;
@@ -780,12 +874,41 @@ struct Engine : EngineBase {
     const int nlev = (int)L.lof->size() - 1;
     const size_t lds = sweep_lds(L.maxk);
     const int mk = std::max(L.maxk, 1);
+    // compulsory traffic of a tile: write y (+ read dense rhs, + read the lidg vector when there is one)
+    const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);   // modes 1-3: rhs is not a 2^k vector
+    if (coop && L.cl && nlev > 1) {
+      const CList& cl = L.cl[tr ? 1 : 0];
+      const int nitems = (int)cl.items.size();
+      REQUIRE(nitems == L.ntiles, "cooperative solve: work list and tile list differ");
+      if (coop_flags.n < (size_t)nitems) {
+        coop_flags.alloc((size_t)nitems + 1024);
+        HIPCHECK(hipMemsetAsync(coop_flags.p, 0, coop_flags.n * sizeof(unsigned), stream));
+      }
+      if (++coop_epoch == 0u) {                                // (wrapped: no stale flag may equal a future epoch)
+        HIPCHECK(hipMemsetAsync(coop_flags.p, 0, coop_flags.n * sizeof(unsigned), stream));
+        coop_epoch = 1u;
+      }
+      coop_slot = (coop_slot + 1) & 7;
+      coop_used = true;
+      timed(MMHN_K_OTHER_SOLVE, per_tile * nitems, [&]() {
+        const dim3 g((unsigned)std::min(nitems, 2 * n_cu)), bk(TSB);
+#define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, coop_flags.p, coop_epoch, coop_ctl.p, coop_slot, h_abort_dev, \
+                y, lidg, rhs, rhs_mode, scal, d_perm.p, mk, L.tab, links.p, qS.p
+        if (lidg) {
+          if (tr) hipLaunchKernelGGL((k_csolve<T, true, true>), CS_ARGS);
+          else hipLaunchKernelGGL((k_csolve<T, false, true>), CS_ARGS);
+        } else {
+          if (tr) hipLaunchKernelGGL((k_csolve<T, true, false>), CS_ARGS);
+          else hipLaunchKernelGGL((k_csolve<T, false, false>), CS_ARGS);
+        }
+#undef CS_ARGS
+      });
+      return;
+    }
     for (int s = 0; s < nlev; ++s) {
       const int lev = tr ? nlev - 1 - s : s;
       const int beg = (*L.lof)[lev], cntl = (*L.lof)[lev + 1] - beg;
       if (cntl == 0) continue;
-      // compulsory traffic of a tile: write y (+ read dense rhs, + read the lidg vector when there is one)
-      const double per_tile = (double)((rhs_mode == 0 ? 2 : 1) + (lidg ? 1 : 0)) * (double)(1 << std::min(L.maxk, TB)) * sizeof(T);   // modes 1-3: rhs is not a 2^k vector
       timed(MMHN_K_OTHER_SOLVE, per_tile * cntl, [&]() {
         const dim3 g(cntl), bk(TSB);
 #define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab, links.p, qS.p
@@ -799,6 +922,17 @@ struct Engine : EngineBase {
 #undef TS_ARGS
       });
     }
+  }
+  // a spin of a cooperative launch timed out (tsolve.h): the results of the evaluation are garbage - fail the call, and put
+  // the words back so that the engine stays usable.  Call after the stream has been synchronised.
+  bool coop_used = false;
+  void check_abort() {
+    if (!coop_used) return;
+    coop_used = false;
+    if (*h_abort == 0u) return;
+    *h_abort = 0u;
+    (void)hipMemset(coop_ctl.p, 0, sizeof(CoopCtl));
+    throw Fail{"cooperative tile solve: a wait for another workgroup's tile timed out (results discarded)"};
   }
 
   // ---------------------------------------------------------------- cohort
@@ -916,7 +1050,6 @@ struct Engine : EngineBase {
         add_tiles(cur.mapJ, pr.j, dj.k);
         cur.maxkJ = std::max(cur.maxkJ, dj.k);
         cur.maxkcJ = std::max(cur.maxkcJ, std::max(popc(dj.maskP), popc(dj.maskM)));
-        cur.max_dl = std::max(cur.max_dl, (1 << popc(dj.maskP & ((1u << TB) - 1u))) + (1 << popc(dj.maskM & ((1u << TB) - 1u))));
         cur.dJ.push_back(dj);
       }
       if (has0) {
@@ -951,31 +1084,42 @@ struct Engine : EngineBase {
         dev.alloc(host.size());
         HIPCHECK(hipMemcpy(dev.p, host.data(), host.size() * sizeof(host[0]), hipMemcpyHostToDevice));
       };
-      build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);
-      b.ptoff.assign(1, 0);
-      b.ptiles.clear();
-      b.all_multi = !b.dJ.empty();
-      for (const Desc& dj : b.dJ)
-        if (!(dj.seedbit >= TB && popc(dj.pairP) <= TB)) b.all_multi = false;
-      b.olist.clear();
-      b.wd.clear();
-      b.wpath = wsolve_mode != 0 && !use_jacobi && (int)b.dJ.size() >= psolve_min && b.all_multi;
-      if (b.wpath) {
-        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
-          if (!window_ok<T>(b.dJ[pj])) { b.olist.push_back((int)pj); continue; }
-          b.wd.push_back(make_wdesc<T>(b.dJ[pj], (int)pj));
+      build_levels(b.mapJ, &b.dJ, !use_jacobi, b.lmapJ, b.lofJ);       // (every joint tile by level: the Jacobi solver's list)
+      const int nJ = (int)b.dJ.size();
+      // ---- routes of the joint problems (Batch::route)
+      auto is_multi = [](const Desc& dj) { return dj.seedbit >= TB && popc(dj.pairP) <= TB; };   // what k_psolve2 takes
+      b.route.assign((size_t)nJ, RT_T);
+      b.olist.clear(); b.wd.clear(); b.wchains.clear();
+      b.wpath = false;
+      if (!use_jacobi && nJ > 0) {
+        int nW = 0, nP = 0;
+        if (wsolve_mode != 0) for (const Desc& dj : b.dJ) nW += window_ok<T>(dj) ? 1 : 0;
+        b.wpath = nW > 0 && nW >= wsolve_min;
+        for (int pj = 0; pj < nJ; ++pj) {
+          if (b.wpath && window_ok<T>(b.dJ[pj])) b.route[pj] = RT_W;
+          else if (is_multi(b.dJ[pj])) ++nP;
         }
-        if (b.wd.empty()) b.wpath = false;
+        if (nP > 0 && nP >= psolve_min)
+          for (int pj = 0; pj < nJ; ++pj) if (b.route[pj] != RT_W && is_multi(b.dJ[pj])) b.route[pj] = RT_P;
+        for (int pj = 0; pj < nJ; ++pj) {
+          if (b.route[pj] == RT_W) b.wd.push_back(make_wdesc<T>(b.dJ[pj], pj));
+          else if (b.route[pj] == RT_P) b.olist.push_back(pj);
+        }
       }
-      b.wchains.clear();
-      if (b.wpath) {
-        // chains (wsolve.h): the window problems sorted by shape, their vectors laid out in that order (the offsets are
-        // the engine's own business: every kernel goes through Desc::off), then cut into about one run per workgroup
+      {
+        // layout of the joint vectors (the offsets are the engine's own business: every kernel goes through Desc::off):
+        // the window problems sorted by shape - a chain of same-shape patients is one contiguous buffer -, then the
+        // per-patient problems, then the tile route's, whose dead tiles must stay zero
         std::stable_sort(b.wd.begin(), b.wd.end(), [](const WDesc& x, const WDesc& y) { return x.kR != y.kR ? x.kR < y.kR : x.kC < y.kC; });
         long long off = 0;
         for (const WDesc& w : b.wd) { b.dJ[w.prob].off = off; off += 1ll << b.dJ[w.prob].k; }
         for (int pj : b.olist) { b.dJ[pj].off = off; off += 1ll << b.dJ[pj].k; }
-        REQUIRE(off == b.vecJ, "window path: offsets of the joint problems do not add up");
+        b.offT = off;
+        for (int pj = 0; pj < nJ; ++pj) if (b.route[pj] == RT_T) { b.dJ[pj].off = off; off += 1ll << b.dJ[pj].k; }
+        REQUIRE(off == b.vecJ, "offsets of the joint problems do not add up");
+      }
+      if (b.wpath) {
+        // chains (wsolve.h): about one run of same-shape problems per workgroup
         const int nW = (int)b.wd.size();
         b.wnx = b.wd[0].nXc + b.wd[0].nXr;
         for (const WDesc& w : b.wd) if (w.nXc + w.nXr != b.wnx) b.wnx = -1;
@@ -1011,16 +1155,19 @@ struct Engine : EngineBase {
             for (size_t r = 0; r < mine[g].size(); ++r) b.wchains[r * (size_t)groups + g] = mine[g][r];
         }
         up(b.d_wd, b.wd);
-        up(b.d_olist, b.olist);
         up(b.d_wchains, b.wchains);
-        b.lmapO.clear(); b.lofO.clear(); b.maxkO = 0;
-        if (!b.olist.empty() && b.olist.size() <= 64) {
-          std::vector<char> left(b.dJ.size(), 0);
-          for (int pj : b.olist) { left[pj] = 1; b.maxkO = std::max(b.maxkO, b.dJ[pj].k); }
-          std::vector<int2> mo;
-          for (const int2& m : b.mapJ) if (left[m.x]) mo.push_back(m);
-          build_levels(mo, &b.dJ, true, b.lmapO, b.lofO);
-          up(b.d_lmapO, b.lmapO);
+      }
+      up(b.d_olist, b.olist);
+      // the tile route: every tile of its problems in one cooperative launch (or level by level)
+      b.lmapT.clear(); b.lofT.clear(); b.maxkT = 0;
+      b.clJ[0].clear(); b.clJ[1].clear();
+      if (!use_jacobi) {
+        std::vector<int2> mt;
+        for (const int2& m : b.mapJ) if (b.route[m.x] == RT_T) { mt.push_back(m); b.maxkT = std::max(b.maxkT, b.dJ[m.x].k); }
+        if (!mt.empty()) {
+          build_levels(mt, &b.dJ, true, b.lmapT, b.lofT);
+          up(b.d_lmapT, b.lmapT);
+          if (b.lofT.size() > 2) { build_clist(mt, b.dJ, true, false, b.clJ[0]); build_clist(mt, b.dJ, true, true, b.clJ[1]); }
         }
       }
       b.mapX.clear();
@@ -1029,36 +1176,67 @@ struct Engine : EngineBase {
         if (popc(dj.maskP) > PCA + PCH || popc(dj.maskM) > PCA + PCH) b.mapX.push_back(m);
       }
       {
-        size_t pos = 0;
-        for (size_t pj = 0; pj < b.dJ.size(); ++pj) {
-          while (pos < b.mapJ.size() && b.mapJ[pos].x == (int)pj) {
-            // k_psolve solves the seed = 0 part of a multi-tile space (only its PT == MT states carry values) as a
-            // small lattice over the paired events, so only the seeded tiles are listed; a single-tile space keeps
-            // its one tile
-            const Desc& dj = b.dJ[pj];
-            const uint32_t Ht = (uint32_t)b.mapJ[pos].y;
-            const bool multi = dj.seedbit >= TB && popc(dj.pairP) <= TB;
-            const bool seeded_tile = multi && ((Ht << TB) >> dj.seedbit) & 1u;
-            if (multi ? seeded_tile : !dead_tile(dj, Ht)) b.ptiles.push_back(Ht);
-            ++pos;
+        // k_psolve2 solves the seed = 0 part of a multi-tile space (only its PT == MT states carry values) as a small
+        // lattice over the paired events, so only the seeded tiles of its problems are listed
+        b.ptoff.assign(1, 0);
+        b.ptiles.clear();
+        b.maxkP = 0; b.max_dl = 0;
+        for (int pj = 0; pj < nJ; ++pj) {
+          const Desc& dj = b.dJ[pj];
+          if (b.route[pj] == RT_P) {
+            const uint32_t nt = 1u << (dj.k - TB);
+            for (uint32_t Ht = 0; Ht < nt; ++Ht) if (((Ht << TB) >> dj.seedbit) & 1u) b.ptiles.push_back(Ht);
+            b.maxkP = std::max(b.maxkP, dj.k);
+            b.max_dl = std::max(b.max_dl, (1 << popc(dj.maskP & ((1u << TB) - 1u))) + (1 << popc(dj.maskM & ((1u << TB) - 1u))));
           }
           b.ptoff.push_back((int)b.ptiles.size());
         }
       }
+      // class marginals of the problems in index order as work items (short launches; a large problem is several
+      // workgroups): per problem its eq block, per class pass the outer loop cut into ranges
+      b.pcl.clear();
+      if (!use_jacobi && nJ <= prep_split_max) {
+        for (int pj = 0; pj < nJ; ++pj) {
+          const Desc& dj = b.dJ[pj];
+          b.pcl.push_back(int4{pj, 2, 0, 0});
+          const int kP = popc(dj.maskP), kM = popc(dj.maskM);
+          if (b.route[pj] == RT_W && wsolve_mode != 2) continue;             // (k_wclass)
+          if (kP > PCA + PCH || kM > PCA + PCH) continue;                     // (k_class_marg)
+          for (int c = 0; c < 2; ++c) {
+            const int kc = c == 0 ? kP : kM, kf = c == 0 ? kM : kP;
+            const int no = pclass_outer_bits(kc, kf), nh = kc > PCA ? kc - PCA : 0;
+            const int per = std::max(1, 16 >> nh);                            // tiles per item: (2^nh class blocks) x (per settings)
+            for (int o0 = 0; o0 < (1 << no); o0 += per) b.pcl.push_back(int4{pj, c, o0, std::min(o0 + per, 1 << no)});
+          }
+        }
+        up(b.d_pcl, b.pcl);
+      }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
-      b.sp_ok = !b.dS.empty();
       b.paired.clear();
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) if (b.pats[pi_].j >= 0) b.paired.push_back((int)pi_);
       up(b.d_paired, b.paired);
+      // ---- single-tumour problems: small-space path for the patients whose spaces all fit a tile, staged kernels for the rest
       for (int w = 0; w < 3; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
+      b.gpats.clear(); b.gpaired.clear(); b.gprobs.clear();
+      b.g_kind2 = false;
+      bool class_fits[SP_NCLASS];
+      for (int c = 0; c < SP_NCLASS; ++c)
+        class_fits[c] = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (size_t)(c == 0 ? SP_PPB0 : c == 1 ? 2 : 1) + 64 <= (size_t)160 * 1024;
+      const bool all_staged = !small_path || use_jacobi;
       for (size_t pi_ = 0; pi_ < b.pats.size(); ++pi_) {
         const PatRec& pr = b.pats[pi_];
         int ks = -1;
         for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) ks = std::max(ks, b.dS[pr.s[part]].k);
         if (ks < 0) continue;
-        if (ks > TB) { b.sp_ok = false; break; }
         int c = 0;
-        while (ks > spatient_class_maxk(c)) ++c;
+        while (c < SP_NCLASS - 1 && ks > spatient_class_maxk(c)) ++c;
+        if (all_staged || ks > TB || !class_fits[c]) {
+          b.gpats.push_back((int)pi_);
+          if (pr.j >= 0) b.gpaired.push_back((int)pi_);
+          for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) b.gprobs.push_back(pr.s[part]);
+          if (pr.kind == 2) b.g_kind2 = true;
+          continue;
+        }
         const bool side_by_side = pair_small && pr.j >= 0 && pr.s[0] >= 0 && pr.s[1] >= 0 && c < 2;
         b.sp_list[side_by_side ? 2 : pr.j >= 0 ? 1 : 0][c].push_back((int)pi_);
       }
@@ -1066,11 +1244,11 @@ struct Engine : EngineBase {
       // launch (its LDS sized for them) - on a small cohort their own launch is a side stream, a fork and a join
       // (~20 us of queue latency) for a handful of patients
       b.mk1p = spatient_class_maxk(1);
-      if (pair_small && b.sp_ok && !b.sp_list[1][2].empty() && b.sp_list[1][2].size() <= 16) {
+      if (pair_small && !b.sp_list[1][2].empty() && b.sp_list[1][2].size() <= 16) {
         int mk = 0;
         for (int pi_ : b.sp_list[1][2])
           for (int part = 0; part < 2; ++part) if (b.pats[pi_].s[part] >= 0) mk = std::max(mk, b.dS[b.pats[pi_].s[part]].k);
-        if (mk <= 10) {
+        if (mk <= 10 && (spatient_lds<T>(N, mk) + 15) / 16 * 16 * 2 + 64 <= (size_t)160 * 1024) {
           for (int pi_ : b.sp_list[1][2]) b.sp_list[b.pats[pi_].s[0] >= 0 && b.pats[pi_].s[1] >= 0 ? 2 : 1][1].push_back(pi_);
           b.sp_list[1][2].clear();
           b.mk1p = mk;
@@ -1089,12 +1267,29 @@ struct Engine : EngineBase {
           for (int c = 0; c < SP_NCLASS; ++c)
             std::stable_sort(b.sp_list[w][c].begin(), b.sp_list[w][c].end(), [&](int x, int y) { return ksize(x) > ksize(y); });
       }
+      b.has_small = false;
       for (int w = 0; w < 3; ++w)
         for (int c = 0; c < SP_NCLASS; ++c) {
-          const size_t need_c = (spatient_lds<T>(N, c == 1 && w ? b.mk1p : spatient_class_maxk(c)) + 15) / 16 * 16 * (c == 0 ? SP_PPB0 : w == 2 ? 2 : 1) + 64;
-          if (!b.sp_list[w][c].empty() && need_c > (size_t)160 * 1024) b.sp_ok = false;
+          if (!b.sp_list[w][c].empty()) b.has_small = true;
           up(b.d_sp_list[w][c], b.sp_list[w][c]);
         }
+      {
+        // lists of the staged kernels
+        std::vector<char> isg(b.dS.size(), 0);
+        for (int sp : b.gprobs) isg[sp] = 1;
+        b.mapG.clear(); b.maxkG = 0; b.tilesG_vec = 0;
+        for (const int2& m : b.mapS) if (isg[m.x]) { b.mapG.push_back(m); b.maxkG = std::max(b.maxkG, b.dS[m.x].k); }
+        for (int sp : b.gprobs) b.tilesG_vec += 1ll << b.dS[sp].k;
+        build_levels(b.mapG, nullptr, false, b.lmapG, b.lofG);
+        b.clG[0].clear(); b.clG[1].clear();
+        if (!use_jacobi && b.lofG.size() > 2) { build_clist(b.mapG, b.dS, false, false, b.clG[0]); build_clist(b.mapG, b.dS, false, true, b.clG[1]); }
+        up(b.d_gpats, b.gpats); up(b.d_gpaired, b.gpaired); up(b.d_gprobs, b.gprobs);
+        up(b.d_mapG, b.mapG); up(b.d_lmapG, b.lmapG);
+        std::vector<int2> gc;
+        for (const int2& e : grad_chunks(b.dS, GK_S)) if (isg[e.x]) gc.push_back(e);
+        up(b.d_grcG, gc);
+        if (gc.empty()) b.d_grcG.release();
+      }
       // the window layout stays in place: every consumer of the joint vectors reads it there (k_gather_marg / the small-space
       // kernels, k_eq_flows, k_wclass); MMHN_WSOLVE=2 converts to index order after each solve instead (k_wconvert)
       b.wdirect = b.wpath && wsolve_mode != 2;
@@ -1129,14 +1324,6 @@ struct Engine : EngineBase {
     GS.alloc(mnS * N * N); zarena.alloc(mZ);
     dots.alloc(2 * mp); bmJ.alloc(mnJ * 64); bmS.alloc(mnS * 64);
     lp.alloc(mp); out.alloc(mp * stride()); redbuf.alloc(((mp + red_per((int)mp) - 1) / red_per((int)mp)) * 2 * (size_t)stride());
-  }
-
-  void fill_e0(const Batch& b) {
-    const int npat = (int)b.pats.size();
-    if (b.dS.empty()) return;
-    hipLaunchKernelGGL((k_fill_e0<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
-                       rhsS.p);
-    HIPCHECK(hipGetLastError());
   }
 
   // ---------------------------------------------------------------- one evaluation
@@ -1223,69 +1410,80 @@ struct Engine : EngineBase {
     }
     for (Batch& b : batches) {
       const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
-      const int tJ = (int)b.mapJ.size(), tS = (int)b.mapS.size();
-      const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};
-      const PList LS{b.d_dS.p, b.d_mapS.p, tS, b.maxkS, b.vecS, b.d_lmapS.p, &b.lofS, tabS.p};
-      const bool fused_small = small_path && !use_jacobi && nS > 0 && b.sp_ok;
-      time_kernels = b.vecJ + b.vecS >= (1ll << 24);
+      const int tJ = (int)b.mapJ.size(), tG = (int)b.mapG.size();
+      const int nG = (int)b.gpats.size(), nGp = (int)b.gprobs.size();
+      const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};       // (Jacobi solver only)
+      // the staged single-tumour problems (Jacobi / MMHN_SMALL=0: all of them, so that vec = every single-tumour vector)
+      const PList LG{b.d_dS.p, b.d_mapG.p, tG, b.maxkG, b.vecS, b.d_lmapG.p, &b.lofG, tabS.p, b.clG};
+      const bool fused_small = b.has_small, staged = nG > 0;
+      (void)nS;
+      time_kernels = b.vecJ + b.vecS >= (1ll << 26);
       const long long gjs = (long long)nJ * N * N;
       GJ.p = zarena.p;
       DJ.p = GJ.p + up4(3 * gjs);
       Abuf.p = DJ.p + up4(3ll * nJ * N);
       if (grad && nJ && !(head_done && &b == &batches.front())) zero(zarena.p, zarena_elems(nJ, b.asize, N));
       prep(b.d_dJ.p, nJ, tabJ.p, true, b.maxkcJ);                    // (first: the head of the critical chain)
+      // the staged kernels add into their problems' gradient rows; the small-space kernels of the other patients store
+      // theirs: cleared before either runs
+      if (staged && grad) {
+        zero(GS.p, (long long)nS * N * N);
+        if (b.g_kind2) zero(bmS.p, (long long)nS * 64);
+      }
       // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
       // run on a side stream from here on, next to the joint forward solve (whose launch is issued first - it is the
       // critical chain); the assembly waits for them
       if (fused_small) small_fork(0);
-      if (!fused_small) prep(b.d_dS.p, nS, tabS.p);        // (k_spatient builds its own tables in LDS)
-      const bool per_patient = !use_jacobi && nJ >= psolve_min;
-      // the tile-level substitution solver skips dead tiles and its consumers read them: those parts of pi / q_J
-      // must hold zeros.  The per-patient kernels never let a value of a dead tile into arithmetic (they are only
-      // ever loaded behind a per-state select), so a batch that runs them needs no clearing - which matters when a
-      // cohort takes several batches per evaluation - but leaves the buffers in an unknown state.
-      if (per_patient) {
-        pi_owner = -1;
-        if (grad) qJ_owner = -1;
-        if (poison) {                                  // MMHN_POISON=1 (tests): NaN-fill instead, any leak shows
-          HIPCHECK(hipMemsetAsync(pi.p, 0xFF, (size_t)b.vecJ * sizeof(T), stream));
-          if (grad) HIPCHECK(hipMemsetAsync(qJ.p, 0xFF, (size_t)b.vecJ * sizeof(T), stream));
-        }
-      } else if (!use_jacobi) {
-        if (pi_owner != b.id) { zero(pi.p, b.vecJ); pi_owner = b.id; }
-        if (grad && qJ_owner != b.id) { zero(qJ.p, b.vecJ); qJ_owner = b.id; }
-      }
-      // 1-2 joint forward
-      if (use_jacobi) launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
-      if (per_patient) psolve(false, b, pi.p, 2);
-      else solve(false, LJ, pi.p, use_jacobi ? lidgJ.p : nullptr, nullptr, 2, nullptr);
-      if (fused_small) small_classes(b, 0, grad);
-      // 3 marginal right-hand sides
-      if (!fused_small) zero(rhsS.p, b.vecS);
-      if (nJ && !fused_small) {                           // (the small-space kernels read pi themselves and write the links)
-        hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.paired.size(), 2, b.maxkS > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
-                           b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_paired.p, b.d_wd.p);
+      if (staged) {                                          // (k_spatient builds its own tables in LDS)
+        hipLaunchKernelGGL((k_prep<T, false>), dim3(nGp), dim3(BLOCK), 0, stream, b.d_dS.p, d_par.p, tabS.p, b.d_gprobs.p);
         HIPCHECK(hipGetLastError());
       }
-      if (fused_small) {
-        small_classes(b, 1, grad);
+      // The tile solver skips dead tiles and its consumers read them: those parts of pi / q_J must hold zeros - the vectors
+      // of the tile route lie behind offT and are cleared once per batch.  The window and per-patient kernels never let a
+      // value of a dead tile into arithmetic (they are only ever loaded behind a per-state select): no clearing, which
+      // matters when a cohort takes several batches per evaluation; MMHN_POISON=1 (tests) NaN-fills their part.
+      if (!use_jacobi && nJ) {
+        if (pi_owner != b.id) { zero(pi.p + b.offT, b.vecJ - b.offT); pi_owner = b.id; }
+        if (grad && qJ_owner != b.id) { zero(qJ.p + b.offT, b.vecJ - b.offT); qJ_owner = b.id; }
+        if (poison && b.offT > 0) {
+          HIPCHECK(hipMemsetAsync(pi.p, 0xFF, (size_t)b.offT * sizeof(T), stream));
+          if (grad) HIPCHECK(hipMemsetAsync(qJ.p, 0xFF, (size_t)b.offT * sizeof(T), stream));
+        }
+      }
+      // 1-2 joint forward
+      if (use_jacobi) {
+        launch_diag(b.d_dJ.p, b.d_mapJ.p, tJ, nullptr, lidgJ.p, nullptr, KD_LIDG);
+        solve(false, LJ, pi.p, lidgJ.p, nullptr, 2, nullptr);
       } else {
-        fill_e0(b);
+        psolve(false, b, pi.p, 2);
+      }
+      if (fused_small) small_classes(b, 0, grad);
+      // 3 marginal right-hand sides of the staged problems (the small-space kernels read pi themselves and write the links)
+      if (staged) {
+        zero(rhsS.p, b.vecS);
+        if (!b.gpaired.empty()) {
+          hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.gpaired.size(), 2, b.maxkG > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
+                             b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_gpaired.p, b.d_wd.p);
+          HIPCHECK(hipGetLastError());
+        }
+      }
+      if (fused_small) small_classes(b, 1, grad);
+      if (staged) {
+        hipLaunchKernelGGL((k_fill_e0<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p, rhsS.p, b.d_gpats.p);
+        HIPCHECK(hipGetLastError());
         // 4 single-tumour spaces
-        launch_diag(b.d_dS.p, b.d_mapS.p, tS, nullptr, lidgS.p, nullptr, KD_LIDG);
-        solve(false, LS, pS.p, lidgS.p, rhsS.p, 0, nullptr);
-        hipLaunchKernelGGL((k_seeds<T>), dim3((npat + 255) / 256), dim3(256), 0, stream, b.d_pats.p, npat, b.d_dS.p,
-                           d_par.p, pS.p, seedS.p, lp.p);
+        launch_diag(b.d_dS.p, b.d_mapG.p, tG, nullptr, lidgS.p, nullptr, KD_LIDG);
+        solve(false, LG, pS.p, lidgS.p, rhsS.p, 0, nullptr);
+        hipLaunchKernelGGL((k_seeds<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p,
+                           d_par.p, pS.p, seedS.p, lp.p, b.d_gpats.p);
         HIPCHECK(hipGetLastError());
       }
       if (grad) {
-        if (!fused_small) {
-          solve(true, LS, qS.p, lidgS.p, nullptr, 1, seedS.p);
-          zero(GS.p, (long long)nS * N * N);
-          launch_grad_rows(b.d_dS.p, nS, b.maxkS, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grc[GK_S]);
-          if (b.has_kind2) {
-            zero(bmS.p, (long long)nS * 64);
-            hipLaunchKernelGGL((k_bit_marg<T>), dim3(tS), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapS.p, d_par.p,
+        if (staged) {
+          solve(true, LG, qS.p, lidgS.p, nullptr, 1, seedS.p);
+          launch_grad_rows(b.d_dS.p, nGp, b.maxkG, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grcG);
+          if (b.g_kind2) {
+            hipLaunchKernelGGL((k_bit_marg<T>), dim3(tG), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapG.p, d_par.p,
                                pS.p, qS.p, bmS.p);
             HIPCHECK(hipGetLastError());
           }
@@ -1293,26 +1491,27 @@ struct Engine : EngineBase {
         if (nJ) {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
-          for (int part = 0; part < 2 && !fused_small; ++part) {
-            hipLaunchKernelGGL((k_scatter_marg<T>), dim3(npat), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
-                               b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part);
+          for (int part = 0; part < 2 && !b.gpaired.empty(); ++part) {
+            hipLaunchKernelGGL((k_scatter_marg<T>), dim3((unsigned)b.gpaired.size()), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
+                               b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part, b.d_gpaired.p);
             HIPCHECK(hipGetLastError());
           }
           if (use_jacobi) solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
-          else if (per_patient) psolve(true, b, qJ.p, 3);
-          else solve(true, LJ, qJ.p, nullptr, nullptr, 3, nullptr);
+          else psolve(true, b, qJ.p, 3);
           // 6 joint gradient (accumulators cleared at the start of the batch)
-          if (per_patient) {
-            // algorithmic bytes: the live (seeded) tiles of pi and q_J read once
-            const double mbytes = 2.0 * (double)b.ptiles.size() * (double)(1 << std::min(b.maxkJ, TB)) * sizeof(T);
+          if (!use_jacobi) {
+            // algorithmic bytes: the seeded halves of pi and q_J read once
+            const double mbytes = (double)b.vecJ * sizeof(T);
             timed(MMHN_K_PCLASS, mbytes, [&]() {
               if (b.wdirect) {                                                  // window-layout problems: both classes, two reads
                 const int nW = (int)b.wd.size();
                 hipLaunchKernelGGL((k_wclass<T>), dim3((unsigned)std::min(nW, n_cu)), dim3(WROWS), wclass_lds<T>(), stream, b.d_dJ.p, b.d_wd.p, nW, pi.p, qJ.p, Abuf.p);
-              }                                                                 // (k_pclass skips them; its SPLIT form still runs their eq flows)
-              if (nJ <= prep_split_max)
-                hipLaunchKernelGGL((k_pclass<T, true>), dim3(nJ, 3), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
-              else
+              }
+              // the problems in index order: work items (class passes of a problem cut into ranges + its eq block's flows)
+              // on short launches, one workgroup per problem on long ones
+              if (!b.pcl.empty())
+                hipLaunchKernelGGL((k_pclass<T, true>), dim3((unsigned)b.pcl.size()), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p, b.d_pcl.p);
+              else if ((int)b.wd.size() < nJ || !b.wdirect)
                 hipLaunchKernelGGL((k_pclass<T, false>), dim3(nJ), dim3(CMB), PC_LDS_ELEMS * sizeof(T), stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
             });
             if (!b.mapX.empty())
@@ -1324,8 +1523,8 @@ struct Engine : EngineBase {
           }
           HIPCHECK(hipGetLastError());
           // (its own launch: folded into the workgroups of k_pclass it cost more than the launch - k_pclass 20.5 -> 21.9 ms
-          // on the bench cohort, the LUAD evaluation +25 us; short launches run it as workgroups of their own in k_pclass)
-          if (!(per_patient && nJ <= prep_split_max)) {
+          // on the bench cohort, the LUAD evaluation +25 us; short launches run it as work items of k_pclass)
+          if (b.pcl.empty()) {
             hipLaunchKernelGGL((k_eq_flows<T>), dim3(nJ), dim3(BLOCK), 0, stream, b.d_dJ.p, b.d_wd.p, pi.p, qJ.p, Abuf.p);
             HIPCHECK(hipGetLastError());
           }
@@ -1357,6 +1556,7 @@ struct Engine : EngineBase {
         std::vector<double> tmp((size_t)npat * st);
         HIPCHECK(hipMemcpyAsync(tmp.data(), out.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
+        check_abort();
         for (int i = 0; i < npat; ++i)
           std::memcpy(host_out + (size_t)b.pats[i].row * st, tmp.data() + (size_t)i * st, st * sizeof(double));
       }
@@ -1366,6 +1566,7 @@ struct Engine : EngineBase {
       std::vector<double> hs(2 * st);
       HIPCHECK(hipMemcpyAsync(hs.data(), sums.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIPCHECK(hipStreamSynchronize(stream));
+      check_abort();
       std::memcpy(host_sums, hs.data(), hs.size() * sizeof(double));
       finish_eval(t0);
     }
@@ -1426,6 +1627,7 @@ struct Engine : EngineBase {
     REQUIRE(expect_len == sums_len, "mmhn_cohort_sums_end / mmhn_cohort_wsums_end does not match the _begin call");
     sums_pending = false;
     HIPCHECK(hipStreamSynchronize(stream));
+    check_abort();
     std::memcpy(o, h_abi, (size_t)sums_len * sizeof(double));
     static const bool trace_host = std::getenv("MMHN_TRACE_HOST") != nullptr;   // diagnostic: host time to issue vs total
     if (trace_host)

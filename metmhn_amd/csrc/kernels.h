@@ -93,11 +93,11 @@ __host__ __device__ inline long long table_size(const Desc& d) {
 
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
-                                                const Params<T>* __restrict__ par, T* tab) {
+                                                const Params<T>* __restrict__ par, T* tab, const int* __restrict__ plist = nullptr) {
   __shared__ T thc[(MAXN + 1) * MAXN];  // later reused as th[i][class bit l]
   __shared__ T rsplit[(MAXN + 1) * 192];  // [i][three 6-bit parts of S] partial rate products (row N: observation)
   __shared__ Desc d;
-  load_desc(&d, descs + blockIdx.x);
+  load_desc(&d, descs + (plist ? plist[blockIdx.x] : (int)blockIdx.x));   // (plist: only these problems of the list)
   __syncthreads();
   const int k = d.k, tid = threadIdx.x;
   const int t = k < TB ? k : TB;
@@ -789,249 +789,12 @@ __global__ __launch_bounds__(KSB, MMHN_KV_WPS) void k_kv(const Desc* __restrict_
   }
 }
 
-// ------------------------------------------------------------------------------------
-// k_tsolve: one tile of the triangular solve  (D - Q) y = rhs   (TR: transposed system).
-//
-// (D - Q) is lower triangular in index order: every transition sets bits, so y[x] only needs
-// y on subsets of x (supersets for the transpose).  Instead of the reference's k+1 Jacobi
-// sweeps (likelihood.py:253-261) each state is computed exactly once:
-//   * tiles are scheduled by levels = popcount of the tile index H (host launches level after
-//     level, ascending; descending for TR), so every neighbour tile H ^ bit is final;
-//   * step A streams the out-of-tile neighbours (coalesced global reads) into an accumulator,
-//   * step B solves the 2^t states of the tile in LDS in popcount order (perm = states sorted
-//     by popcount, one barrier per level): z = acc + sum rate * y[x ^ move], y = lidg * z,
-//   * step C writes the tile back.
-// Same result as the Jacobi iteration up to rounding (Q_off is nilpotent), 1/(k+1) of the
-// arithmetic and ~1/10 of the HBM traffic.
-// ------------------------------------------------------------------------------------
 #ifndef MMHN_TSB
 #define MMHN_TSB 1024
 #endif
-constexpr int TSB = MMHN_TSB;                // threads per workgroup of k_tsolve / k_psolve
+constexpr int TSB = MMHN_TSB;                // threads per workgroup of the tile solvers (tsolve.h) and of k_psolve2
 constexpr int TSB_WPE = TSB == 1024 ? 8 : 4; // waves per SIMD the register budget is sized for (two workgroups per CU)
 
-
-// LIDGV: 1/(D - diag Q) comes from the vector `lidg` (API path, single-tumour spaces);
-// otherwise from the class tables of k_prep (joint spaces with seeding: engine path).
-template <typename T, bool TR, bool LIDGV>
-__global__ __launch_bounds__(TSB, TSB_WPE) void k_tsolve(const Desc* __restrict__ descs,
-                                                const int2* __restrict__ lmap,
-                                                const Params<T>* __restrict__ par, T* y,
-                                                const T* __restrict__ lidg,
-                                                const T* __restrict__ rhs, int rhs_mode,
-                                                const T* __restrict__ scal,
-                                                const uint16_t* __restrict__ perm,
-                                                const int* __restrict__ lvl, int maxk,
-                                                const T* __restrict__ tab,
-                                                const JLink<T>* __restrict__ links,
-                                                const T* __restrict__ qS) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  Desc& d = *reinterpret_cast<Desc*>(smem);
-  T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
-  T* Ltab = yt + (1 << TB);
-  T* Utab = Ltab + maxk * 64;
-  const int tid = threadIdx.x;
-  const uint32_t blk = xcd_chunked(blockIdx.x, gridDim.x);
-  const int prob = lmap[blk].x;
-  const uint32_t H = (uint32_t)lmap[blk].y;
-  load_desc(&d, descs + prob);
-  __syncthreads();
-  const int k = d.k;
-  const int t = k < TB ? k : TB;
-  const uint32_t nelem = 1u << t, tmask = nelem - 1;
-  const long long base = d.off;
-  const uint32_t xhi = H << t;
-  const bool joint = d.mode == JOINT;
-  constexpr int NJ = (1 << TB) / TSB;        // states per thread
-  constexpr int NW = TSB / 64;
-  // ---- step-B operands of this thread's states (perm order), fetched first so that their
-  // latency hides behind the table load and step A: state index and 1/(D - diag Q)
-  const uint16_t* pm = perm + (size_t)t * (1 << TB);
-  uint32_t px[NJ];
-  T lid[NJ];
-  T rhs3[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) rhs3[j] = 0;
-  if (LIDGV) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t idx = (uint32_t)tid + TSB * j;
-      px[j] = idx < nelem ? pm[idx] : 0u;
-      lid[j] = idx < nelem ? lidg[base + xhi + px[j]] : T(0);
-    }
-  } else {
-    const T* dP = tab + d.toff + rate_table_size(k);
-    const T* dM = dP + (1ll << __popc(d.maskP));
-    const T* dE = dM + (1ll << __popc(d.maskM));
-    const uint32_t cP = d.maskP & tmask, cM = d.maskM & tmask, cE = d.pairP & tmask;
-    // pext of the 12 tile bits through two 64-entry tables per mask (low 6 / high 6 bits of xl);
-    // entries 384..386: compact index of the tile's high class bits (tile-uniform, computed once)
-    uint32_t* pxt = reinterpret_cast<uint32_t*>(Utab);         // Utab is filled later by tile_tables
-    if (tid < 384) {
-      const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
-      const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
-      const uint32_t part = half == 0 ? pext32((uint32_t)v, m & 63u)
-                                      : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
-      pxt[tid] = part;
-    } else if (tid < 387) {
-      const uint32_t m = tid == 384 ? d.maskP : tid == 385 ? d.maskM : d.pairP;
-      pxt[tid] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
-    }
-    __syncthreads();
-    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t idx = (uint32_t)tid + TSB * j;
-      px[j] = idx < nelem ? pm[idx] : 0u;
-      const uint32_t xl = px[j], x = xhi | xl;
-      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
-      T v = 1;
-      if (idx < nelem) {
-        if ((x >> d.seedbit) & 1u) v = T(1) / (dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
-        else if (eq_noseed(d, x)) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
-      }
-      lid[j] = v;      // seed = 0 states with PT != MT: no rates and zero right-hand side, y stays 0
-    }
-    if (rhs_mode == 3) {
-      // right-hand side of the joint adjoint, formed on the fly: only the compatible states (all bits of the
-      // observed tumour + seeding set) are non-zero and take D * q_marginal[pext(x, other tumour's bits)]
-      const JLink<T> L = links[prob];
-      const bool seed_hi = (xhi >> d.seedbit) & 1u;
-      const bool can0 = L.soff[0] >= 0 && (d.seedbit < t || seed_hi) && ((xhi & d.maskP & ~tmask) == (d.maskP & ~tmask));
-      const bool can1 = L.soff[1] >= 0 && (d.seedbit < t || seed_hi) && ((xhi & d.maskM & ~tmask) == (d.maskM & ~tmask));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t xl = ((uint32_t)((tid >> 6) + NW * j) << 6) | (uint32_t)(tid & 63);
-        const uint32_t x = xhi | xl;
-        T rv = 0;
-        if (xl < nelem && ((x >> d.seedbit) & 1u)) {
-          const uint32_t lo = xl & 63u, hi6 = xl >> 6;
-          if (can0 && (xl & cP) == cP) rv += L.cst[0] * qS[L.soff[0] + (1ll << (L.sk[0] - 1)) + ((hM | pxt[128 + lo] | pxt[192 + hi6]))];
-          if (can1 && (xl & cM) == cM) rv += L.cst[1] * qS[L.soff[1] + (1ll << (L.sk[1] - 1)) + ((hP | pxt[lo] | pxt[64 + hi6]))];
-        }
-        rhs3[j] = rv;
-      }
-    }
-    __syncthreads();   // pxt lives in the Utab area: done before tile_tables overwrites it
-  }
-  tile_tables(d, tab, H, Ltab, Utab, yt);
-
-  const int wave = tid >> 6, lane = tid & 63;
-  const uint32_t last = (1u << k) - 1u;
-
-  // ---- step A: right-hand side + transitions that cross the tile boundary
-  T acc[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-    T rv = 0;
-    if (xl < nelem) {
-      const uint32_t x = xhi | xl;
-      if (rhs_mode == 0) rv = rhs[base + x];
-      else if (rhs_mode == 1) rv = (x == last) ? scal[prob] : T(0);
-      else if (rhs_mode == 2) rv = (x == 0) ? e0_scale<T>() : T(0);
-      else rv = rhs3[j];
-    }
-    acc[j] = rv;
-  }
-  for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
-    const int c = d.cls[b];
-    const bool is_seed = joint && c == CS;
-    const bool is_pair = joint && ((d.pairP >> b) & 1u);
-    // candidate moves of bit b: single bit (async / seeding) and, for a paired P bit, both bits
-    for (int kind = 0; kind < 2; ++kind) {
-      if (kind == 1 && !is_pair) continue;
-      const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
-      const uint32_t mh = mv >> t, ml = mv & tmask;
-      if (mh == 0) continue;                                   // stays inside the tile: step B
-      if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;       // tile-uniform part of the condition
-      const T Lb = Ltab[b * 64 + lane];
-      T nv[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {                           // all neighbour loads in flight together
-        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-        nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int r = wave + NW * j;
-        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-        const uint32_t x = xhi | xl;
-        const bool ss = seed_set(d, x);
-        bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
-        if (kind == 1) cond = cond && !ss && eq_noseed(d, x);
-        else if (is_seed) cond = cond && eq_noseed(d, x);
-        else cond = cond && ss;
-        const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
-        acc[j] += cond ? term : T(0);
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-    if (xl < nelem) yt[xl] = acc[j];
-  }
-  __syncthreads();
-
-  // ---- step B: popcount-ordered substitution inside the tile (a state's level is its popcount)
-  const uint32_t pairP = joint ? d.pairP : 0u;
-  const uint32_t lone = d.lone;
-  const int seedb = joint ? d.seedbit : -1;
-  // fast tiles: every in-tile bit is a plain single-bit move for every state (single-tumour spaces, and
-  // joint tiles whose seeding bit lies above the tile and is set) - no per-bit condition logic at all
-  const bool fast = !joint || (seedb >= t && ((xhi >> seedb) & 1u));
-  int plev[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) plev[j] = ((uint32_t)tid + TSB * j) < nelem ? __popc(px[j]) : -1;
-  for (int s = 0; s <= t; ++s) {
-    const int level = TR ? t - s : s;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (plev[j] != level) continue;
-      const uint32_t xl = px[j];
-      const uint32_t lo = xl & 63u, ro = xl >> 6;
-      T z = yt[xl];
-      uint32_t todo = TR ? (~xl & tmask) : xl;
-      if (fast) {
-        while (todo) {                         // three bits per trip: their 9 LDS loads are issued together
-          T r[3];
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            const bool on = todo != 0;
-            const int b = on ? __ffs(todo) - 1 : 0;
-            todo &= todo - 1;                  // 0 stays 0
-            const T v = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ (1u << b)];
-            r[u] = on ? v : T(0);
-          }
-          z += r[0] + r[1] + r[2];
-        }
-      } else {
-        const uint32_t x = xhi | xl;
-        const bool ss = seedb >= 0 && ((x >> seedb) & 1u);
-        const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
-        while (todo) {
-          const int b = __ffs(todo) - 1;
-          todo &= todo - 1;
-          uint32_t mv = 1u << b;
-          bool cond;
-          if (b == seedb) cond = e0x;
-          else if (ss) cond = true;
-          else if ((pairP >> b) & 1u) {
-            mv = 3u << b;
-            cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
-          } else cond = false;
-          if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
-        }
-      }
-      yt[xl] = lid[j] * z;
-    }
-    __syncthreads();
-  }
-
-  // ---- step C
-  for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
-}
 
 // 1 / v for a positive, normal-range v (sums of rates): hardware reciprocal + two Newton steps (full precision
 // for fp64, no scaling / fix-up sequence of the IEEE division)
@@ -1056,12 +819,13 @@ __device__ __forceinline__ long long sgpr64(long long v) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_psolve: the same triangular solve, one workgroup per PATIENT.
+// One workgroup per PATIENT (k_psolve2 below; round 1's k_psolve, which also took partial and seed-inside tiles, is gone
+// since round 5: those problems take the cooperative tile launch of tsolve.h).
 //
 // With hundreds of patients in flight there is no need for parallelism inside a patient: index order is itself a
 // valid substitution order (every neighbour H ^ bit of a tile has a smaller tile index; larger for the
-// transpose), so one workgroup walks its patient's live tiles in that order.  Descriptor, rate tables, pext
-// tables and the popcount permutation are set up once per patient instead of once per tile, the solve is a
+// transpose), so one workgroup walks its patient's live tiles in that order.  Descriptor, rate tables and pext
+// tables are set up once per patient instead of once per tile, the solve is a
 // single launch, and the neighbour tiles a tile reads were written moments earlier by the same CU.
 // Joint spaces with seeding only (class-table diagonal; right-hand side e_0 or the on-the-fly adjoint rhs).
 // ------------------------------------------------------------------------------------
@@ -1096,349 +860,7 @@ __device__ unsigned long long g_stamps[16];
 #ifndef MMHN_Q_LANES
 #define MMHN_Q_LANES 2        // lanes that share one group of k_psolve2's in-tile solve (1, 2 or 4)
 #endif
-constexpr int PS_DL2 = 1040;                    // the same for k_psolve2 (no 8 KiB permutation in LDS): up to 2^10 + 2^4 entries
-constexpr int PS_DL = 528;                      // most LDS entries k_psolve spends on the per-tile dP / dM slices (2^9 + 2^3 ... 2^6 + 2^6)
-
-// MULTI: every problem of the launch is a multi-tile space whose seed = 0 part takes the lattice solve, so every
-// listed tile is a full seeded one and the per-state (generic) paths are compiled out
-template <typename T, bool TR, bool MULTI>
-__global__ __launch_bounds__(TSB, TSB_WPE) void k_psolve(const Desc* __restrict__ descs,
-                                                   const int* __restrict__ pt_off,
-                                                   const uint32_t* __restrict__ ptiles,
-                                                   const Params<T>* __restrict__ par, T* y, int rhs_mode,
-                                                   const uint16_t* __restrict__ perm, int maxk,
-                                                   const T* __restrict__ tab,
-                                                   const JLink<T>* __restrict__ links,
-                                                   const T* __restrict__ qS, int dl_cap,
-                                                    const int* __restrict__ plist) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  Desc& d = *reinterpret_cast<Desc*>(smem);
-  T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
-  T* Ltab = yt + (1 << TB) + 2;                                 // yt[1 << TB] stays 0: target of padded reads
-  T* Urow = Ltab + maxk * 64;
-  T* Utab = Urow + maxk * 64;
-  T* thc = Utab + maxk * 64;
-  T* hx = thc + maxk * maxk;
-  uint32_t* pxt = reinterpret_cast<uint32_t*>(hx + maxk);       // 384 pext entries
-  uint16_t* pml = reinterpret_cast<uint16_t*>(pxt + 400);       // popcount order of the tile's states
-  T* dl = reinterpret_cast<T*>(pml + (1 << TB));                // this tile's slices of the dP / dM tables (dl_cap entries)
-  const int tid0 = threadIdx.x;
-  int tid = tid0;
-  const int prob = plist ? plist[blockIdx.x] : (int)blockIdx.x;   // (plist: the batch's problems that stay on the tile kernels)
-  load_desc(&d, descs + prob);
-  __syncthreads();
-  const int k = sgpr(d.k);
-  const int t = MULTI ? TB : (k < TB ? k : TB);            // MULTI: full tiles only, the bounds below fold away
-  const uint32_t nelem = 1u << t, tmask = nelem - 1;
-  const long long base = sgpr64(d.off);
-  const long long toff = sgpr64(d.toff);
-  const uint32_t maskP = sgpr(d.maskP), maskM = sgpr(d.maskM);
-  constexpr int NJ = (1 << TB) / TSB;
-  constexpr int NW = TSB / 64;
-  // ---- once per patient: tables, pext lookups, popcount order of this thread's states
-  {
-    const T* src = tab + toff;
-    for (int e = tid; e < k * k; e += TSB) thc[e] = src[e];
-    for (int e = tid; e < k * 64; e += TSB) { Ltab[e] = src[k * k + e]; Urow[e] = src[k * k + k * 64 + e]; }
-  }
-  const uint32_t pairP = sgpr(d.pairP), lone = sgpr(d.lone);
-  const int seedb = sgpr(d.seedbit);
-  const uint32_t cP = maskP & tmask, cM = maskM & tmask, cE = pairP & tmask;
-  if (tid == 0) yt[1 << TB] = T(0);
-  if (tid < 384) {
-    const int which = tid >> 7, half = (tid >> 6) & 1, v = tid & 63;
-    const uint32_t m = which == 0 ? cP : which == 1 ? cM : cE;
-    pxt[tid] = half == 0 ? pext32((uint32_t)v, m & 63u) : (pext32((uint32_t)v << 6, m & ~63u) << __popc(m & 63u));
-  }
-  {
-    const uint16_t* pm = perm + (size_t)t * (1 << TB);
-    for (uint32_t e = tid; e < nelem; e += TSB) pml[e] = pm[e];
-  }
-  const T* dP = tab + toff + rate_table_size(k);
-  const T* dM = dP + (1ll << __popc(maskP));
-  const T* dE = dM + (1ll << __popc(maskM));
-  const int nPin = __popc(cP), nMin = __popc(cM);
-  // a seeded tile needs 2^nPin + 2^nMin consecutive entries of dP / dM: staged in LDS when they fit
-  const bool dl_ok = (1 << nPin) + (1 << nMin) <= dl_cap;   // dl_cap: what the launch could afford (<= PS_DL)
-  const int t0 = pt_off[prob], ntile = pt_off[prob + 1] - t0;
-  JLink<T> Lk;
-  if (rhs_mode == 3) Lk = links[prob];
-  __syncthreads();
-
-  // ---- seed = 0 part of a multi-tile space: only the states with PT == MT (both bits of a subset e of the paired
-  // events, nothing else) carry values; they form a lattice over the ke paired events that is solved here in yt,
-  // level by level, one state per thread - before the seeded tiles (which read it through the seeding move) in the
-  // forward solve, after them (it reads their q through the transposed seeding move) in the transposed one.
-  // The other states of the seed = 0 half are never written and never reach arithmetic.
-  const int ke = __popc(pairP);
-  const bool eq_block = seedb >= t && t == TB && ke <= TB;
-  auto solve_eq_block = [&]() {
-    const uint32_t VE = 1u << ke;
-    const T seed_base = thc[seedb * k + seedb];
-    for (int s = 0; s <= ke; ++s) {
-      const int level = TR ? ke - s : s;
-      for (uint32_t e = tid0; e < VE; e += TSB) {
-        if (__popc(e) != level) continue;
-        const uint32_t xp = pdep32(e, pairP);
-        const uint32_t x0 = xp | (xp << 1);
-        T z = (!TR && e == 0) ? e0_scale<T>() : T(0);
-        if (!TR) {
-          for (uint32_t m = xp; m; m &= m - 1) {                 // synchronised event of pair bit b into x0
-            const int bP = __ffs(m) - 1;
-            T r = thc[bP * k + bP];
-            for (uint32_t m2 = xp & ~(1u << bP); m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
-            z += r * yt[pext32(xp & ~(1u << bP), pairP)];
-          }
-        } else {
-          for (uint32_t m = pairP & ~xp; m; m &= m - 1) {        // ... out of x0
-            const int bP = __ffs(m) - 1;
-            T r = thc[bP * k + bP];
-            for (uint32_t m2 = xp; m2; m2 &= m2 - 1) r *= thc[bP * k + (__ffs(m2) - 1)];
-            z += r * yt[pext32(xp | (1u << bP), pairP)];
-          }
-          T rs = seed_base;                                       // seeding out of x0 (into a seeded tile, already solved)
-          for (uint32_t m2 = xp; m2; m2 &= m2 - 1) rs *= thc[seedb * k + (__ffs(m2) - 1)];
-          z += rs * y[base + (x0 | (1u << seedb))];
-        }
-        const T v = z / dE[e];
-        yt[e] = v;
-        y[base + x0] = v;
-      }
-      __syncthreads();
-    }
-  };
-  STAMP_DECL;
-  STAMP_START;
-  if (eq_block && !TR) solve_eq_block();
-  STAMP(7);
-  uint32_t Hprev = 0xffffffffu;                                 // tile whose solution yt still holds
-  for (int it = 0; it < ntile; ++it) {
-    STAMP_START;
-    const uint32_t H = ptiles[t0 + (TR ? ntile - 1 - it : it)];
-    const uint32_t xhi = H << t;
-    // keep nothing thread-dependent live across tiles (64 VGPRs for two workgroups per CU): everything below is
-    // re-derived from an opaque copy of the thread index
-    tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int wave = tid >> 6, lane = tid & 63;
-    // ---- per tile: the slices of the diagonal tables this tile needs are fetched now and land in LDS behind the
-    // next barrier (no table gather on the critical path after step A)
-    const bool fastt = MULTI || (t == TB && seedb >= t && ((xhi >> seedb) & 1u));
-    T dval = 0;
-    const int dli = tid - 128;
-    if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) {
-      const bool isM = dli >= (1 << nPin);
-      const uint32_t m = isM ? maskM : maskP;
-      const uint32_t hi = pext32(xhi, m & ~tmask) << __popc(m & tmask);
-      dval = isM ? dM[hi | (uint32_t)(dli - (1 << nPin))] : dP[hi | (uint32_t)dli];
-    }
-    // ---- per tile: tile-bit factors, compact high parts of the class indices
-    if (tid < k) {
-      T h = thc[tid * k + tid];
-      for (int bb = t; bb < k; ++bb) if (bb != tid && ((H >> (bb - t)) & 1u)) h *= thc[tid * k + bb];
-      hx[tid] = h;
-    } else if (tid >= 64 && tid < 67) {
-      const uint32_t m = tid == 64 ? maskP : tid == 65 ? maskM : pairP;
-      pxt[384 + tid - 64] = pext32(xhi, m & ~tmask) << __popc(m & tmask);
-    }
-    __syncthreads();
-    STAMP(0);
-    for (int e = tid; e < k * 64; e += TSB) Utab[e] = Urow[e] * hx[e >> 6];
-    if (fastt && dl_ok && dli >= 0 && dli < (1 << nPin) + (1 << nMin)) dl[dli] = dval;
-    const bool seed_hi = (xhi >> seedb) & 1u;
-    const uint32_t hP = pxt[384], hM = pxt[385], hE = pxt[386];
-    // ---- right-hand side
-    T acc[NJ];
-    if (rhs_mode == 3) {
-      const bool can0 = Lk.soff[0] >= 0 && (seedb < t || seed_hi) && ((xhi & maskP & ~tmask) == (maskP & ~tmask));
-      const bool can1 = Lk.soff[1] >= 0 && (seedb < t || seed_hi) && ((xhi & maskM & ~tmask) == (maskM & ~tmask));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-        const uint32_t x = xhi | xl;
-        T rv = 0;
-        if (xl < nelem && ((x >> seedb) & 1u)) {
-          const uint32_t lo = xl & 63u, hi6 = xl >> 6;
-          if (can0 && (xl & cP) == cP) rv += Lk.cst[0] * qS[Lk.soff[0] + (1ll << (Lk.sk[0] - 1)) + (hM | pxt[128 + lo] | pxt[192 + hi6])];
-          if (can1 && (xl & cM) == cM) rv += Lk.cst[1] * qS[Lk.soff[1] + (1ll << (Lk.sk[1] - 1)) + (hP | pxt[lo] | pxt[64 + hi6])];
-        }
-        acc[j] = rv;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-        acc[j] = (xl < nelem && (xhi | xl) == 0) ? e0_scale<T>() : T(0);
-      }
-    }
-    __syncthreads();                                   // Utab complete; the previous tile's stores have landed
-    STAMP(1);
-    const bool fast = MULTI || (t == TB && seedb >= t && seed_hi);
-    // ---- step A: transitions that cross the tile boundary
-    // one move (bit b; kind 1 = the pair move of P bit b) with every condition evaluated per state
-    auto gen_move = [&](int b, int kind) {
-      const bool is_seed = b == seedb;
-      const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
-      const uint32_t mh = mv >> t, ml = mv & tmask;
-      if (mh == 0) return;
-      if (TR ? (H & mh) != 0 : (H & mh) != mh) return;
-      const T Lb = Ltab[b * 64 + lane];
-      T nv[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-        nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int r = wave + NW * j;
-        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
-        const uint32_t x = xhi | xl;
-        const bool ss = (x >> seedb) & 1u;
-        const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
-        bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
-        if (kind == 1) cond = cond && !ss && e0x;
-        else if (is_seed) cond = cond && e0x;
-        else cond = cond && ss;
-        const T term = Lb * Utab[b * 64 + (r & 63)] * nv[j];
-        acc[j] += cond ? term : T(0);
-      }
-    };
-    if (fast) {
-      // seeded full tile: pair moves never apply and a single-bit move above the tile applies to every state;
-      // the move list is a scalar bit set of the tile index
-      uint32_t mb = (TR ? ~H : H) & ((1u << (k - t)) - 1u) & ~(1u << (seedb - t));
-      while (mb) {
-        const int b = t + __ffs(mb) - 1;
-        mb &= mb - 1;
-        const T Lb = Ltab[b * 64 + lane];
-        T nf[NJ];
-        if ((H ^ (1u << (b - t))) == Hprev) {
-          // the neighbour is the tile this workgroup solved last: still in yt (this thread's own slots)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) nf[j] = yt[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
-        } else {
-          const T* yn = y + base + (xhi ^ (1u << b));
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) nf[j] = yn[((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane];
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j] += Lb * Utab[b * 64 + wave + NW * j] * nf[j];
-      }
-      if (!TR && seed_move_possible(lone, pairP, xhi, tmask)) gen_move(seedb, 0);
-    } else if constexpr (!MULTI) {
-      for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
-        gen_move(b, 0);
-        if ((pairP >> b) & 1u) gen_move(b, 1);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
-      if (xl < nelem) yt[xl] = acc[j];
-    }
-    STAMP(2);
-    // popcount order of this thread's states and their inverse diagonals (after step A: registers are tight)
-    uint32_t px[NJ];
-    int plev[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t idx = (uint32_t)tid + TSB * j;
-      px[j] = idx < nelem ? pml[idx] : 0u;
-      plev[j] = idx < nelem ? __popc(px[j]) : -1;
-    }
-    T lid[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const uint32_t xl = px[j], x = xhi | xl;
-      const uint32_t lo = xl & 63u, hi6 = xl >> 6;
-      T v = 1;
-      if (plev[j] >= 0) {
-        if (fast && dl_ok) v = fast_rcp(dl[pxt[lo] | pxt[64 + hi6]] + dl[(1 << nPin) + (pxt[128 + lo] | pxt[192 + hi6])]);
-        else if ((x >> seedb) & 1u) v = fast_rcp(dP[hP | pxt[lo] | pxt[64 + hi6]] + dM[hM | pxt[128 + lo] | pxt[192 + hi6]]);
-        else if (((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)))) v = T(1) / dE[hE | pxt[256 + lo] | pxt[320 + hi6]];
-      }
-      lid[j] = v;
-    }
-    __syncthreads();
-    STAMP(3);
-    // ---- step B: popcount-ordered substitution inside the tile
-    for (int s = 0; s <= t; ++s) {
-      const int level = TR ? t - s : s;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (plev[j] != level) continue;
-        const uint32_t xl = px[j];
-        const uint32_t lo = xl & 63u, ro = xl >> 6;
-        T z = yt[xl];
-        uint32_t todo = TR ? (~xl & tmask) : xl;
-        if (fast) {
-          constexpr int TPT = (MULTI && !TR) ? 4 : 3;      // terms per trip (what the register budget allows)
-          while (todo) {
-            T lv[TPT], uv[TPT], yv[TPT];
-#pragma unroll
-            for (int u = 0; u < TPT; ++u) {
-              const bool on = todo != 0;
-              const int b = on ? __ffs(todo) - 1 : 0;
-              todo &= todo - 1;
-              const uint32_t yi = on ? (xl ^ (1u << b)) : (1u << TB);      // padded slot reads the zero
-              lv[u] = Ltab[b * 64 + lo];
-              uv[u] = Utab[b * 64 + ro];
-              yv[u] = yt[yi];
-            }
-            asm volatile("" ::: "memory");                 // all LDS reads of the trip in flight before the first use
-            T zz = lv[0] * uv[0] * yv[0];
-#pragma unroll
-            for (int u = 1; u < TPT; ++u) zz += lv[u] * uv[u] * yv[u];
-            z += zz;
-          }
-        } else if constexpr (!MULTI) {
-          const uint32_t x = xhi | xl;
-          const bool ss = (x >> seedb) & 1u;
-          const bool e0x = ((x & lone) == 0) && (((x & pairP) << 1) == (x & (pairP << 1)));
-          while (todo) {
-            const int b = __ffs(todo) - 1;
-            todo &= todo - 1;
-            uint32_t mv = 1u << b;
-            bool cond;
-            if (b == seedb) cond = e0x;
-            else if (ss) cond = true;
-            else if ((pairP >> b) & 1u) {
-              mv = 3u << b;
-              cond = (b + 1 < t) && e0x && (TR ? (xl & mv) == 0 : (xl & mv) == mv);
-            } else cond = false;
-            if (cond) z += Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[(xl ^ mv) & tmask];
-          }
-        }
-        yt[xl] = lid[j] * z;
-      }
-      __syncthreads();
-    }
-    STAMP(4);
-    // ---- step C: 16 bytes per lane when the tile is full
-    if (t == TB) {
-      struct alignas(16) vec16 { T v[16 / sizeof(T)]; };
-      constexpr uint32_t PER = 16 / sizeof(T);
-      for (uint32_t e = (uint32_t)tid * PER; e < nelem; e += TSB * PER)
-        *reinterpret_cast<vec16*>(y + base + xhi + e) = *reinterpret_cast<const vec16*>(yt + e);
-    } else {
-      for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
-    }
-    Hprev = H;
-    // LDS-only barrier (Utab / yt are rewritten next); the stores are waited for by the full barrier that
-    // precedes the next tile's neighbour loads
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    STAMP(5);
-  }
-  STAMP_START;
-  if (eq_block && TR) {
-    __syncthreads();                                             // the seeded tiles' q has landed
-    solve_eq_block();
-  }
-  STAMP(7);
-  STAMP_FLUSH(TR ? 8 : 0);
-}
+constexpr int PS_DL2 = 1040;                    // most LDS entries k_psolve2 spends on the per-tile dP / dM slices: up to 2^10 + 2^4
 
 // sum_{i < l} C(n, i): offset of popcount level l in the popcount-sorted list of the n-bit states
 template <int N>
@@ -2132,9 +1554,10 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
                                                         const Params<T>* __restrict__ par,
                                                         const T* __restrict__ qS,
                                                         const T* __restrict__ rhsS, T* rhsJ,
-                                                        T* dots, int part) {
+                                                        T* dots, int part, const int* __restrict__ plist) {
   __shared__ T red[BLOCK];
-  const PatRec pr = pats[blockIdx.x];
+  const int pat = plist ? plist[blockIdx.x] : (int)blockIdx.x;     // (plist: the patients on the staged kernels)
+  const PatRec pr = pats[pat];
   if (pr.j < 0 || pr.s[part] < 0) return;
   const Desc& dj = dJ[pr.j];
   const Desc& ds = dS[pr.s[part]];
@@ -2155,15 +1578,16 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dots[2 * blockIdx.x + part] = red[0];
+  if (threadIdx.x == 0) dots[2 * pat + part] = red[0];
 }
 
 // e_0 right-hand sides of the unpaired patients' own single-tumour problems
 template <typename T>
-__global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS, T* rhsS) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npat) return;
-  const PatRec pr = pats[i];
+__global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS, T* rhsS,
+                          const int* __restrict__ plist) {
+  const int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= npat) return;
+  const PatRec pr = pats[plist ? plist[ii] : ii];
   if (pr.kind <= 2 && pr.s[0] >= 0) rhsS[dS[pr.s[0]].off] = e0_scale<T>();
 }
 
@@ -2171,9 +1595,10 @@ __global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc*
 template <typename T>
 __global__ void k_seeds(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS,
                         const Params<T>* __restrict__ par, const T* __restrict__ pS, T* seedS,
-                        double* lp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npat) return;
+                        double* lp, const int* __restrict__ plist) {
+  const int ii = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ii >= npat) return;
+  const int i = plist ? plist[ii] : ii;                    // (plist: the patients on the staged kernels)
   const PatRec pr = pats[i];
   if (pr.kind == 4) return;
   T full = 0;
@@ -2420,16 +1845,27 @@ __device__ __forceinline__ uint32_t low_bits(uint32_t m, int n) {
   return r;
 }
 
+// the outer loop of a class pass (host: Engine::pclass_items mirrors it): o runs over the settings of the other class's bits
+// above the tile
+__host__ __device__ inline int pclass_outer_bits(int kc, int kf) {
+  const int a = kc < PCA ? kc : PCA;
+  const int nfl = kf < TB - a ? kf : TB - a;
+  return kf - nfl;
+}
+
+// SPLIT: the launch runs over work items {problem, 0 / 1: class pass, 2: the eq block's flows (k_eq_flows), o0, o1: range of
+// the pass's outer loop} - short launches are one workgroup's chain long, and a large problem is several workgroups (their
+// partial sums meet in the atomics of the flush).  Otherwise one workgroup per problem does both passes.
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, const WDesc* __restrict__ wds, const T* __restrict__ p,
-                                                   const T* __restrict__ q, T* A) {
+                                                   const T* __restrict__ q, T* A, const int4* __restrict__ items = nullptr) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* pt = reinterpret_cast<T*>(smem);
   T* qt = pt + (1 << TB) + PC_PAD * 64;                  // + 2^(PCA-1) slack behind it for the neighbour reads
-  const Desc& d = dJ[blockIdx.x];
-  // SPLIT (gridDim.y == 3): a workgroup per class pass and one for the eq block's flows (k_eq_flows) - short launches,
-  // whose length is one workgroup's chain
-  if (SPLIT && blockIdx.y == 2) { eq_flows_body(d, wds, p, q, A, (int)threadIdx.x, CMB); return; }
+  int4 item = int4{(int)blockIdx.x, 0, 0, 0};
+  if (SPLIT) item = items[blockIdx.x];
+  const Desc& d = dJ[item.x];
+  if (SPLIT && item.y == 2) { eq_flows_body(d, wds, p, q, A, (int)threadIdx.x, CMB); return; }
   const int seedbit = d.seedbit;
   if (seedbit < 0 || d.wl >= 0) return;                   // (window-layout problems: k_wclass)
   const int k = d.k;
@@ -2444,7 +1880,7 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
   constexpr int NST = (1 << TB) / CMB;
   constexpr int NROW = (1 << TB) / 64 / NWV;              // rows per wave of a full tile
   const int kP = __popc(maskP);
-  for (int c = SPLIT ? (int)blockIdx.y : 0; c < (SPLIT ? (int)blockIdx.y + 1 : 2); ++c) {
+  for (int c = SPLIT ? item.y : 0; c < (SPLIT ? item.y + 1 : 2); ++c) {
     const uint32_t cmask = c == 0 ? maskP : maskM;
     const uint32_t other = allbits & ~cmask;
     const int kc = __popc(cmask), kf = __popc(other);
@@ -2486,7 +1922,7 @@ __global__ __launch_bounds__(CMB, 4) void k_pclass(const Desc* __restrict__ dJ, 
         for (int j = 0; j < (HI ? PCH : 1); ++j) acch[s][j] = T(0);
       }
       const uint32_t cbase = pdep32(Shi, chigh);
-      for (uint32_t o = 0; o < (1u << no); ++o) {
+      for (uint32_t o = SPLIT ? (uint32_t)item.z : 0u; o < (SPLIT ? (uint32_t)item.w : (1u << no)); ++o) {
         const uint32_t obase = sbm | pdep32(o, omask);
         {
           const long long base = off + (long long)(obase | cbase);
