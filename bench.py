@@ -58,8 +58,12 @@ def parse():
     ap.add_argument("--n", type=int, default=20, help="events (k = n active bits per patient)")
     ap.add_argument("--patients", type=int, default=5000, help="patients per GPU")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--workload", default="full-k", choices=["full-k", "luad"],
-                    help="full-k: BASELINE configs[2]; luad: the LUAD-reduced cohort of configs[0] (small-k regime)")
+    ap.add_argument("--workload", default="full-k", choices=["full-k", "luad", "luad28"],
+                    help="full-k: BASELINE configs[2]; luad: the LUAD-reduced cohort of configs[0] (small-k regime); luad28: the "
+                         "28-event LUAD cohort the reference's examples/analysis.py fits (heterogeneous, k up to 21)")
+    ap.add_argument("--min-seconds", type=float, default=5.0,
+                    help="the timed region is repeated in whole multiples of --steps until it has lasted this long (steps_run in "
+                         "the line; value and ms_per_step stay per step)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="patients timed on the reference-structure CPU baseline (-1: two per core)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -187,6 +191,15 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+def luad28_cohort():
+    """The 28-event LUAD cohort (4 852 x 59 int8, tests/golden/luad28.npz: derived from the reference's data/luad CSVs as
+    examples/analysis.py:49-72 does, by tests/tools/make_golden_luad.py luad28) at the reference's published parameters
+    (results/luad/luad_g14_cv_20muts_8cnvs.csv)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "luad28.npz"))
+    return (g["dat"], g["fit_theta"], g["fit_dp"], g["fit_dm"], float(g["perc_met"]),
+            "28-event LUAD cohort of examples/analysis.py (tests/golden/luad28.npz), published parameters", g)
+
+
 def luad_cohort(n_default=20):
     """The LUAD-reduced cohort (4 852 x 43 int8, tests/golden/luad_indep.npz: data derived from the reference's
     data/luad CSVs by tests/tools/make_golden_luad.py) and the `indep` start; a synthetic cohort of the same
@@ -198,6 +211,62 @@ def luad_cohort(n_default=20):
     from metmhn_amd import synthetic
     lt, dp, dm = synthetic.random_params(n_default)
     return synthetic.mixed_cohort(n_default, 4852, seed=3), lt, dp, dm, 0.2, "synthetic mixed cohort, 4 852 rows (fixture absent)"
+
+
+def real_cohort_leg(ro, note, reps=20):
+    """One evaluation of the 28-event LUAD cohort: ms per evaluation (value + gradient, score only), the result against the
+    fixture, and a per-kernel breakdown of ONE evaluation timed with HIP events around the solve / class-marginal launches (a
+    second engine with MMHN_TIME_KERNELS=1: the events cost host time, so the breakdown's evaluation is slower than the
+    untimed one quoted as ms_per_eval)."""
+    from metmhn_amd import Engine
+    dat, lt, dp, dm, pm, name, g = luad28_cohort()
+    n = (dat.shape[1] - 3) // 2
+    sp = np.concatenate((np.asarray(lt).flatten(), dp, dm))
+    v, gr = ro.score_and_grad_reg(sp, dat, pm, ro.symmetric_penal, 1e-3)
+    err_v = abs(float(v) - float(g["fit_reg_value"])) / abs(float(g["fit_reg_value"]))
+    err_g = float(np.max(np.abs(gr - g["fit_reg_grad"])) / np.max(np.abs(g["fit_reg_grad"])))
+    ts, tsc = [], []
+    for _ in range(reps):
+        t1 = time.perf_counter()
+        ro.score_and_grad_reg(sp, dat, pm, ro.symmetric_penal, 1e-3)
+        ts.append(time.perf_counter() - t1)
+    for _ in range(reps):
+        t1 = time.perf_counter()
+        ro.score_reg(sp, dat, pm, ro.symmetric_penal, 1e-3)
+        tsc.append(time.perf_counter() - t1)
+    k = dat[dat[:, -1] == 3][:, :2 * n + 1].sum(1)
+    out = {"workload": name, "rows": int(dat.shape[0]), "paired_rows": int((dat[:, -1] == 3).sum()), "k_max": int(k.max()),
+           "paired_rows_k_ge_13": int((k >= 13).sum()), "seeded_states": float((2.0 ** (k - 1)).sum()),
+           "ms_per_eval_with_grad": float(np.median(ts) * 1e3), "ms_per_eval_score_only": float(np.median(tsc) * 1e3),
+           "evals_per_s": float(1.0 / np.median(ts)),
+           "check": {"against": "tests/golden/luad28.npz (oracle/metmhn_ref.c on every row)", "rel_err_value": err_v,
+                     "rel_err_grad_max": err_g, "tolerance": 1e-7}}
+    os.environ["MMHN_TIME_KERNELS"] = "1"
+    try:
+        e = Engine(n)
+        e.set_cohort(dat)
+        e.cohort_sums(lt, dp, dm)
+        e.reset_counters()
+        nrep = 5
+        for _ in range(nrep):
+            e.cohort_sums(lt, dp, dm)
+        c = e.counters()
+        e.close()
+    finally:
+        del os.environ["MMHN_TIME_KERNELS"]
+    names = {"csolve_fwd": "k_csolve<double,false> (joint forward solve: tiles of every paired patient in one cooperative launch)",
+             "csolve_adj": "k_csolve<double,true> (joint adjoint solve)",
+             "pclass": "k_pclass<double> (class marginals as work items: a large patient is several workgroups)",
+             "other_solve": "k_csolve / k_tsolve (single-tumour spaces of more than a tile: forward + adjoint)",
+             "psolve_fwd": "k_wsolve / k_psolve2 forward (not used by this cohort)", "psolve_adj": "k_wsolve / k_psolve2 adjoint"}
+    bd = {}
+    for key, label in names.items():
+        if c[key]["launches"]:
+            bd[key] = {"kernel": label, "ms_per_eval": c[key]["ms"] / nrep, "launches_per_eval": c[key]["launches"] / nrep,
+                       "alg_bytes_per_eval": c[key]["alg_bytes"] / nrep}
+    out["kernel_breakdown"] = bd
+    out["kernel_breakdown_eval_ms"] = c["eval_ms"] / nrep
+    return out
 
 
 def main():
@@ -226,8 +295,8 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    if a.workload == "luad":
-        dat, lt, dp, dm, perc_met, wl_name = luad_cohort()
+    if a.workload in ("luad", "luad28"):
+        dat, lt, dp, dm, perc_met, wl_name = luad_cohort() if a.workload == "luad" else luad28_cohort()[:6]
         n = (dat.shape[1] - 3) // 2
         dat = np.vstack([dat] * world)
         unit_rows = dat.shape[0] // world
@@ -260,12 +329,28 @@ def main():
         step()
         note("warmup step done")
     eng.reset_counters()
+    # The timed region: EXACTLY a.steps steps between two fences - repeated (whole multiples of a.steps, every rank the same
+    # count) until it has lasted --min-seconds, so that a driver sampling the GPU from outside sees it busy for seconds, not
+    # for the 0.25 s of five steps.  Every figure of the line stays per step.
+    reps = 1
+    if a.min_seconds > 0:
+        fence()
+        t0 = time.perf_counter()
+        step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps = max(1, int(np.ceil(a.min_seconds / max(float(t.item()) * a.steps, 1e-9))))
+        eng.reset_counters()
+    steps_run = reps * a.steps
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps_run):
         val, grad = step()
     fence()
     dt = time.perf_counter() - t0
+    steps_asked, a.steps = a.steps, steps_run                  # (every per-step figure below divides by the steps that ran)
     rank_ms = [dt / a.steps * 1e3]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -361,13 +446,14 @@ def main():
         dominant = rf_fwd or rf_other or {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
         out = {
             "metric": "full-cohort log-lik+grad evals/sec at n=20 events; kronvec HBM GB/s",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": steps_asked, "steps_run": steps_run, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if a.config == 2 else "strong", "vs_baseline": None,
             "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
-            "dtype": a.dtype, "data": "synthetic" if a.workload == "full-k" else "LUAD-reduced genotypes (derived fixture), indep() parameters",
+            "dtype": a.dtype, "data": "synthetic" if a.workload == "full-k" else "LUAD genotypes (derived fixture), indep() / published parameters",
             "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
+                       "rccl_ranks": cnt.get("comm_ranks", 0), "rccl_rank": cnt.get("comm_rank", -1),
                        "solver": os.environ.get("MMHN_SOLVER", "substitution (k_wsolve: window layout, chains of patients; k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
             # dominant kernel of the timed step
@@ -451,6 +537,13 @@ def main():
             except Exception as exc:
                 out["small_cohort"] = {"error": repr(exc)}
             note("small-cohort leg done")
+            # ---- the reference's real workload: the 28-event LUAD cohort examples/analysis.py fits (heterogeneous: paired rows
+            # with k = 1 .. 21, single-tumour spaces of up to 17 bits) - per-problem dispatch + the cooperative tile launch
+            try:
+                out["real_cohort"] = real_cohort_leg(ro, note)
+            except Exception as exc:
+                out["real_cohort"] = {"error": repr(exc)}
+            note("real-cohort leg done")
         if world == 1 and not a.no_cpu and a.workload == "full-k":
             out["cpu_baseline"] = cpu_baseline(n, a.patients, a.cpu_sample)
             note("cpu baseline (reference structure) done")
@@ -478,7 +571,7 @@ def main():
                 import gc
                 gc.collect()
                 cmd = [sys.executable, os.path.abspath(__file__), "--n", "25", "--dtype", "f32", "--patients", "768", "--steps", "2",
-                       "--warmup", "1", "--no-cpu", "--no-extras"]
+                       "--warmup", "1", "--min-seconds", "0", "--no-cpu", "--no-extras"]
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 line = json.loads(res.stdout.strip().splitlines()[-1])
                 out["config4_batch"] = {

@@ -177,11 +177,13 @@ int mmhn_simulate(mmhn_handle h, const double* log_theta, const double* pt_d_ef,
  * mmhn_get_counters: cumulative figures since mmhn_reset_counters, per class of dominant kernel (events recorded
  * on the engine's stream around every launch).
  */
-enum { MMHN_K_OTHER_SOLVE = 0,  /* per-tile solves / Jacobi sweeps (k_tsolve, k_sweep): marginal problems, small batches */
-       MMHN_K_PSOLVE_FWD = 1,   /* k_psolve forward: one workgroup per patient, (D - Q) pi = e_0 */
-       MMHN_K_PSOLVE_ADJ = 2,   /* k_psolve adjoint: (D - Q)^T q = rhs */
-       MMHN_K_PCLASS = 3,       /* k_pclass: class marginals of pi (x) q */
-       MMHN_K_COUNT = 4 };
+enum { MMHN_K_OTHER_SOLVE = 0,  /* tile solves / Jacobi sweeps of the single-tumour problems (k_csolve, k_tsolve, k_sweep), API calls */
+       MMHN_K_PSOLVE_FWD = 1,   /* k_wsolve / k_psolve2 forward: a chain of patients / one patient per workgroup, (D - Q) pi = e_0 */
+       MMHN_K_PSOLVE_ADJ = 2,   /* ... adjoint: (D - Q)^T q = rhs */
+       MMHN_K_PCLASS = 3,       /* k_wclass / k_pclass: class marginals of pi (x) q */
+       MMHN_K_CSOLVE_FWD = 4,   /* k_csolve forward: the tiles of the joint problems on the tile route, one cooperative launch */
+       MMHN_K_CSOLVE_ADJ = 5,   /* ... adjoint */
+       MMHN_K_COUNT = 6 };
 typedef struct {
   double ms;         /* total duration of the launches (HIP events on the engine's stream) */
   int64_t launches;
@@ -192,11 +194,13 @@ typedef struct {
   mmhn_kernel_counter kernel[MMHN_K_COUNT];
   double eval_ms;    /* host wall time spent inside evaluations */
   int64_t evals;
+  int32_t comm_ranks; /* ranks of the RCCL communicator attached by mmhn_comm_init as RCCL itself reports them (ncclCommCount), 0: none */
+  int32_t comm_rank;  /* this engine's rank in it (ncclCommUserRank), -1: none */
 } mmhn_counters;
-/* ABI version of this header: bumped whenever an exported signature changes (4: mmhn_bench_kronvec has its `tiles`
- * argument, mmhn_debug_lane_moves exists).  A client built against another header must refuse to run:
+/* ABI version of this header: bumped whenever an exported signature or structure changes (4: mmhn_bench_kronvec has its
+ * `tiles` argument, mmhn_debug_lane_moves exists; 5: mmhn_counters has six kernel classes and the communicator's size / rank).  A client built against another header must refuse to run:
  * mmhn_abi_version() != MMHN_ABI_VERSION (metmhn_amd/_lib.py checks it on load). */
-#define MMHN_ABI_VERSION 4
+#define MMHN_ABI_VERSION 5
 int mmhn_abi_version(void);
 int mmhn_bench_kronvec(mmhn_handle h, const double* log_theta, const int8_t* state, int64_t batch,
                        int iters, int transpose, int jacobi, double* ms_per_launch, int64_t* tiles);

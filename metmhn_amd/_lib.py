@@ -22,7 +22,7 @@ i8p = C.POINTER(C.c_int8)
 i64p = C.POINTER(C.c_int64)
 
 
-KERNEL_CLASSES = ("other_solve", "psolve_fwd", "psolve_adj", "pclass")      # MMHN_K_* of include/metmhn_amd.h
+KERNEL_CLASSES = ("other_solve", "psolve_fwd", "psolve_adj", "pclass", "csolve_fwd", "csolve_adj")      # MMHN_K_* of include/metmhn_amd.h
 
 
 class KernelCounter(C.Structure):
@@ -30,7 +30,8 @@ class KernelCounter(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [("kernel", KernelCounter * len(KERNEL_CLASSES)), ("eval_ms", C.c_double), ("evals", C.c_int64)]
+    _fields_ = [("kernel", KernelCounter * len(KERNEL_CLASSES)), ("eval_ms", C.c_double), ("evals", C.c_int64),
+                ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32)]
 
 
 # name -> argtypes (every function returns int status unless noted)
@@ -74,7 +75,7 @@ SIGNATURES = {
     "mmhn_debug_lane_moves": [C.c_void_p, C.c_int, C.POINTER(C.c_int)],
 }
 OTHER_SYMBOLS = ("mmhn_destroy", "mmhn_last_error", "mmhn_abi_version")
-ABI_VERSION = 4          # MMHN_ABI_VERSION of include/metmhn_amd.h these prototypes were written against
+ABI_VERSION = 5          # MMHN_ABI_VERSION of include/metmhn_amd.h these prototypes were written against
 
 
 def needs_build() -> bool:

@@ -93,6 +93,20 @@ struct CList {
 };
 enum Route : uint8_t { RT_W = 0, RT_P = 1, RT_T = 2 };
 
+// the lists of the staged single-tumour kernels for one group of patients of a batch
+struct Staged {
+  std::vector<int> pats, paired, probs;      // patients; those of them with a joint problem; their single-tumour problems
+  DevArr<int> d_pats, d_paired, d_probs;
+  std::vector<int2> map, lmap;               // tiles of the problems (map order / by level)
+  std::vector<int> lof;
+  DevArr<int2> d_map, d_lmap;
+  DevArr<int2> d_grc;                        // k_grad_rows work list (GK_S)
+  CList cl[2];                               // cooperative work lists, forward / transposed
+  int maxk = 0;
+  bool kind2 = false;                        // a patient of the group is an MT-only row
+  bool empty() const { return pats.empty(); }
+};
+
 // static (per cohort) description of one batch of patients
 struct Batch {
   std::vector<PatRec> pats;
@@ -123,15 +137,8 @@ struct Batch {
   int mk1p = 9;                  // bits the 256-thread class of the paired rows is sized for (spatient_class_maxk(1) or up to 10)
   // ... the other patients (a single-tumour space of more than a tile; MMHN_SMALL=0 / the Jacobi solver: every patient)
   // take the staged kernels over these lists
-  std::vector<int> gpats, gpaired, gprobs;   // staged patients; those of them with a joint problem; their single-tumour problems
-  DevArr<int> d_gpats, d_gpaired, d_gprobs;
-  std::vector<int2> mapG, lmapG;             // tiles of the staged problems (map order / by level)
-  std::vector<int> lofG;
-  DevArr<int2> d_mapG, d_lmapG;
-  DevArr<int2> d_grcG;                       // k_grad_rows work list (GK_S) of the staged problems
-  int maxkG = 0;
-  long long tilesG_vec = 0;                  // elements of the staged problems' vectors (Jacobi pricing)
-  bool g_kind2 = false;                      // a staged patient is an MT-only row
+  // [0]: patients that are their own problem (nothing of the joint path feeds them: a side stream), [1]: paired rows
+  Staged stg[2];
   std::vector<int> paired;       // patients with a joint problem
   DevArr<int> d_paired;
   // ---- per-problem dispatch of the joint solves (round 5).  Every joint problem takes ONE of three routes:
@@ -149,7 +156,7 @@ struct Batch {
   std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
   DevArr<WChain> d_wchains;
   long long offT = 0;            // the RT_T problems' vectors start here (the tile solver skips their dead tiles: kept zero)
-  CList clJ[2], clG[2];          // cooperative work lists, forward / transposed: RT_T joint tiles; staged single-tumour tiles
+  CList clJ[2];                  // cooperative work lists of the RT_T tiles, forward / transposed
   std::vector<int2> lmapT;       // the RT_T tiles by level (MMHN_COOP=0: one launch per level)
   std::vector<int> lofT;
   DevArr<int2> d_lmapT;
@@ -312,6 +319,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -330,6 +339,8 @@ static Rccl& rccl() {
   r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
   r.lib = lib;
@@ -481,8 +492,8 @@ struct Engine : EngineBase {
   DevArr<int> d_lvl;
   bool use_jacobi = false;      // MMHN_SOLVER=jacobi: the reference's k+1 sweeps instead of substitution
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
-  hipStream_t side[2] = {};               // side streams of the small-space path
-  hipEvent_t ev_fork[2] = {}, ev_join[2] = {};
+  hipStream_t side[3] = {};               // side streams: [0], [1] of the small-space path, [2] of the staged own-problem patients
+  hipEvent_t ev_fork[3] = {}, ev_join[3] = {};
   int kv_version = 2;           // MMHN_KV=1: the round-1 kronvec kernel (k_sweep) also for plain products on multi-tile spaces
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int prep_split_max = 2048;    // MMHN_PREP_SPLIT: problems up to which k_prep / k_pclass run a workgroup per table / class pass
@@ -491,13 +502,17 @@ struct Engine : EngineBase {
                                 // per patient (k_psolve2) instead of the cooperative tile launch (MMHN_PSOLVE_MIN)
   int wsolve_min = 128;         // window-shaped joint problems in a batch from which they take the window route (MMHN_WSOLVE_MIN;
                                 // follows MMHN_PSOLVE_MIN when only that one is set)
+  bool force_timing = false;    // MMHN_TIME_KERNELS=1: HIP events around the solve / class-marginal launches of every batch (bench
+                                // breakdowns of small cohorts; an event pair costs the host ~10 us)
+  int coop_wgs = 0;             // MMHN_COOP_WGS: workgroups of a cooperative launch (default: two per CU)
   bool coop = true;             // MMHN_COOP=0: tile solves as one launch per level (k_tsolve) instead of one cooperative launch
   // cooperative launches (tsolve.h): queue heads + abort word, the flags of the tiles (value = epoch of the launch that
   // finished the tile), the pinned host copy of the abort word
   DevArr<CoopCtl> coop_ctl;
-  DevArr<unsigned> coop_flags;
+  DevArr<unsigned> coop_flags[2];   // one set per lane: launches of two streams may be in flight together
   unsigned coop_epoch = 0;
   int coop_slot = 0;
+  int cur_lane = 0;                 // lane of the launches being issued (1: a side stream)
   unsigned* h_abort = nullptr;
   unsigned* h_abort_dev = nullptr;
   int wsolve_chain = 1;         // MMHN_WSOLVE_CHAIN=0: every window problem its own chain (the pipeline drains between patients)
@@ -515,6 +530,7 @@ struct Engine : EngineBase {
 
   Engine(int dev, int n_mut) : n(n_mut), N(n_mut + 1) {
     device = dev;
+    cnt.comm_rank = -1;
     REQUIRE(n_mut >= 1 && n_mut < MAXN, "n_mut must be in [1, 31]");
     DevGuard guard(device);
     HIPCHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -547,6 +563,8 @@ struct Engine : EngineBase {
       if (const char* pm = std::getenv("MMHN_PSOLVE_MIN")) { psolve_min = std::atoi(pm); wsolve_min = psolve_min; }
       if (const char* pm = std::getenv("MMHN_WSOLVE_MIN")) wsolve_min = std::atoi(pm);
       if (const char* pm = std::getenv("MMHN_COOP")) coop = std::atoi(pm) != 0;
+      if (const char* pm = std::getenv("MMHN_TIME_KERNELS")) force_timing = std::atoi(pm) != 0;
+      if (const char* pm = std::getenv("MMHN_COOP_WGS")) coop_wgs = std::atoi(pm);
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PAIR_SMALL")) pair_small = std::atoi(sp) != 0;
@@ -578,7 +596,7 @@ struct Engine : EngineBase {
     *h_abort = 0u;
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient2<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spatient<T, 1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
       HIPCHECK(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
       HIPCHECK(hipEventCreateWithFlags(&ev_fork[i], hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
@@ -611,7 +629,7 @@ struct Engine : EngineBase {
   ~Engine() override {                       // runs under the DevGuard of mmhn_destroy
     comm_destroy();
     for (auto& e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
       if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
       if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
       if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -668,7 +686,9 @@ struct Engine : EngineBase {
   // (tables of more than 2^13 entries - k = 25 - are also cut into parts of 2^13: grid.y = 4 * parts)
   void prep(const Desc* descs, int nprob, T* tab, bool joint = false, int maxkc = 0) {
     if (nprob == 0) return;
-    const int parts = maxkc > 13 ? 1 << (maxkc - 13) : 1;
+    // SPLIT: a table of more than 2^9 entries is dealt over several workgroups (the launch is the head of every evaluation
+    // of a short cohort; at most 32 parts: the workgroups of the shorter tables of the launch exit at once, but they are launched)
+    const int parts = maxkc > 9 ? 1 << std::min(maxkc - 9, 5) : 1;
     if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4 * parts), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
@@ -798,6 +818,7 @@ struct Engine : EngineBase {
     const Desc* d; const int2* map; int ntiles; int maxk; long long vec;
     const int2* lmap; const std::vector<int>* lof; const T* tab;
     const CList* cl = nullptr;
+    int kslot = MMHN_K_OTHER_SOLVE;    // counter class of its launches
   };
 
   // k_psolve2 (one workgroup per patient, all-seeded-tile launches)
@@ -853,7 +874,8 @@ struct Engine : EngineBase {
     }
     if (!b.lmapT.empty()) {
       // everything else: all tiles in one cooperative launch (several workgroups per patient)
-      const PList LT{b.d_dJ.p, nullptr, (int)b.lmapT.size(), b.maxkT, 0, b.d_lmapT.p, &b.lofT, tabJ.p, b.clJ};
+      const PList LT{b.d_dJ.p, nullptr, (int)b.lmapT.size(), b.maxkT, 0, b.d_lmapT.p, &b.lofT, tabJ.p, b.clJ,
+                     tr ? MMHN_K_CSOLVE_ADJ : MMHN_K_CSOLVE_FWD};
       solve(tr, LT, y, nullptr, nullptr, rhs_mode, nullptr);
     }
   }
@@ -880,19 +902,23 @@ struct Engine : EngineBase {
       const CList& cl = L.cl[tr ? 1 : 0];
       const int nitems = (int)cl.items.size();
       REQUIRE(nitems == L.ntiles, "cooperative solve: work list and tile list differ");
-      if (coop_flags.n < (size_t)nitems) {
-        coop_flags.alloc((size_t)nitems + 1024);
-        HIPCHECK(hipMemsetAsync(coop_flags.p, 0, coop_flags.n * sizeof(unsigned), stream));
+      DevArr<unsigned>& flags = coop_flags[cur_lane];
+      if (flags.n < (size_t)nitems) {
+        HIPCHECK(hipStreamSynchronize(stream));                // (a launch of this lane may still poll the old array)
+        flags.alloc((size_t)nitems + 1024);
+        HIPCHECK(hipMemsetAsync(flags.p, 0, flags.n * sizeof(unsigned), stream));
       }
       if (++coop_epoch == 0u) {                                // (wrapped: no stale flag may equal a future epoch)
-        HIPCHECK(hipMemsetAsync(coop_flags.p, 0, coop_flags.n * sizeof(unsigned), stream));
+        HIPCHECK(hipDeviceSynchronize());
+        for (auto& f : coop_flags) if (f.p) HIPCHECK(hipMemset(f.p, 0, f.n * sizeof(unsigned)));
         coop_epoch = 1u;
       }
-      coop_slot = (coop_slot + 1) & 7;
+      coop_slot = (coop_slot + 1) & 3;
+      const int slot = cur_lane * 4 + coop_slot;
       coop_used = true;
-      timed(MMHN_K_OTHER_SOLVE, per_tile * nitems, [&]() {
-        const dim3 g((unsigned)std::min(nitems, 2 * n_cu)), bk(TSB);
-#define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, coop_flags.p, coop_epoch, coop_ctl.p, coop_slot, h_abort_dev, \
+      timed(L.kslot, per_tile * nitems, [&]() {
+        const dim3 g((unsigned)std::min(nitems, coop_wgs > 0 ? coop_wgs : CS_WG_PER_CU * n_cu)), bk(TSB);
+#define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, flags.p, coop_epoch, coop_ctl.p, slot, h_abort_dev, \
                 y, lidg, rhs, rhs_mode, scal, d_perm.p, mk, L.tab, links.p, qS.p
         if (lidg) {
           if (tr) hipLaunchKernelGGL((k_csolve<T, true, true>), CS_ARGS);
@@ -909,7 +935,7 @@ struct Engine : EngineBase {
       const int lev = tr ? nlev - 1 - s : s;
       const int beg = (*L.lof)[lev], cntl = (*L.lof)[lev + 1] - beg;
       if (cntl == 0) continue;
-      timed(MMHN_K_OTHER_SOLVE, per_tile * cntl, [&]() {
+      timed(L.kslot, per_tile * cntl, [&]() {
         const dim3 g(cntl), bk(TSB);
 #define TS_ARGS L.d, L.lmap + beg, d_par.p, y, lidg, rhs, rhs_mode, scal, d_perm.p, d_lvl.p, mk, L.tab, links.p, qS.p
         if (lidg) {
@@ -1217,8 +1243,7 @@ struct Engine : EngineBase {
       up(b.d_paired, b.paired);
       // ---- single-tumour problems: small-space path for the patients whose spaces all fit a tile, staged kernels for the rest
       for (int w = 0; w < 3; ++w) for (int c = 0; c < SP_NCLASS; ++c) b.sp_list[w][c].clear();
-      b.gpats.clear(); b.gpaired.clear(); b.gprobs.clear();
-      b.g_kind2 = false;
+      for (int w = 0; w < 2; ++w) { Staged& g = b.stg[w]; g.pats.clear(); g.paired.clear(); g.probs.clear(); g.kind2 = false; }
       bool class_fits[SP_NCLASS];
       for (int c = 0; c < SP_NCLASS; ++c)
         class_fits[c] = (spatient_lds<T>(N, spatient_class_maxk(c)) + 15) / 16 * 16 * (size_t)(c == 0 ? SP_PPB0 : c == 1 ? 2 : 1) + 64 <= (size_t)160 * 1024;
@@ -1231,10 +1256,12 @@ struct Engine : EngineBase {
         int c = 0;
         while (c < SP_NCLASS - 1 && ks > spatient_class_maxk(c)) ++c;
         if (all_staged || ks > TB || !class_fits[c]) {
-          b.gpats.push_back((int)pi_);
-          if (pr.j >= 0) b.gpaired.push_back((int)pi_);
-          for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) b.gprobs.push_back(pr.s[part]);
-          if (pr.kind == 2) b.g_kind2 = true;
+          // (MMHN_SMALL=0 / Jacobi: one group on the main stream - its solver clears and sweeps whole buffers)
+          Staged& g = b.stg[all_staged || pr.j >= 0 ? 1 : 0];
+          g.pats.push_back((int)pi_);
+          if (pr.j >= 0) g.paired.push_back((int)pi_);
+          for (int part = 0; part < 2; ++part) if (pr.s[part] >= 0) g.probs.push_back(pr.s[part]);
+          if (pr.kind == 2) g.kind2 = true;
           continue;
         }
         const bool side_by_side = pair_small && pr.j >= 0 && pr.s[0] >= 0 && pr.s[1] >= 0 && c < 2;
@@ -1273,22 +1300,21 @@ struct Engine : EngineBase {
           if (!b.sp_list[w][c].empty()) b.has_small = true;
           up(b.d_sp_list[w][c], b.sp_list[w][c]);
         }
-      {
+      for (int w = 0; w < 2; ++w) {
         // lists of the staged kernels
+        Staged& g = b.stg[w];
         std::vector<char> isg(b.dS.size(), 0);
-        for (int sp : b.gprobs) isg[sp] = 1;
-        b.mapG.clear(); b.maxkG = 0; b.tilesG_vec = 0;
-        for (const int2& m : b.mapS) if (isg[m.x]) { b.mapG.push_back(m); b.maxkG = std::max(b.maxkG, b.dS[m.x].k); }
-        for (int sp : b.gprobs) b.tilesG_vec += 1ll << b.dS[sp].k;
-        build_levels(b.mapG, nullptr, false, b.lmapG, b.lofG);
-        b.clG[0].clear(); b.clG[1].clear();
-        if (!use_jacobi && b.lofG.size() > 2) { build_clist(b.mapG, b.dS, false, false, b.clG[0]); build_clist(b.mapG, b.dS, false, true, b.clG[1]); }
-        up(b.d_gpats, b.gpats); up(b.d_gpaired, b.gpaired); up(b.d_gprobs, b.gprobs);
-        up(b.d_mapG, b.mapG); up(b.d_lmapG, b.lmapG);
+        for (int sp : g.probs) isg[sp] = 1;
+        g.map.clear(); g.maxk = 0;
+        for (const int2& m : b.mapS) if (isg[m.x]) { g.map.push_back(m); g.maxk = std::max(g.maxk, b.dS[m.x].k); }
+        build_levels(g.map, nullptr, false, g.lmap, g.lof);
+        g.cl[0].clear(); g.cl[1].clear();
+        if (!use_jacobi && g.lof.size() > 2) { build_clist(g.map, b.dS, false, false, g.cl[0]); build_clist(g.map, b.dS, false, true, g.cl[1]); }
+        up(g.d_pats, g.pats); up(g.d_paired, g.paired); up(g.d_probs, g.probs);
+        up(g.d_map, g.map); up(g.d_lmap, g.lmap);
         std::vector<int2> gc;
         for (const int2& e : grad_chunks(b.dS, GK_S)) if (isg[e.x]) gc.push_back(e);
-        up(b.d_grcG, gc);
-        if (gc.empty()) b.d_grcG.release();
+        up(g.d_grc, gc);
       }
       // the window layout stays in place: every consumer of the joint vectors reads it there (k_gather_marg / the small-space
       // kernels, k_eq_flows, k_wclass); MMHN_WSOLVE=2 converts to index order after each solve instead (k_wconvert)
@@ -1410,14 +1436,45 @@ struct Engine : EngineBase {
     }
     for (Batch& b : batches) {
       const int npat = (int)b.pats.size(), nJ = (int)b.dJ.size(), nS = (int)b.dS.size();
-      const int tJ = (int)b.mapJ.size(), tG = (int)b.mapG.size();
-      const int nG = (int)b.gpats.size(), nGp = (int)b.gprobs.size();
+      const int tJ = (int)b.mapJ.size();
       const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};       // (Jacobi solver only)
-      // the staged single-tumour problems (Jacobi / MMHN_SMALL=0: all of them, so that vec = every single-tumour vector)
-      const PList LG{b.d_dS.p, b.d_mapG.p, tG, b.maxkG, b.vecS, b.d_lmapG.p, &b.lofG, tabS.p, b.clG};
-      const bool fused_small = b.has_small, staged = nG > 0;
-      (void)nS;
-      time_kernels = b.vecJ + b.vecS >= (1ll << 26);
+      const bool fused_small = b.has_small, staged = !b.stg[0].empty() || !b.stg[1].empty();
+      const bool kind2g = b.stg[0].kind2 || b.stg[1].kind2;
+      // the staged kernels of one group of patients (Batch::stg): forward part (tables, right-hand sides, 1/diag, forward solve,
+      // scores and adjoint seeds) and gradient part (adjoint solve, gradient rows, observation-rate marginals)
+      auto staged_fwd = [&](const Staged& g) {
+        if (g.empty()) return;
+        const int nG = (int)g.pats.size(), tG = (int)g.map.size();
+        // (Jacobi / MMHN_SMALL=0: the group is every single-tumour problem, so that vec = every single-tumour vector)
+        const PList LG{b.d_dS.p, g.d_map.p, tG, g.maxk, b.vecS, g.d_lmap.p, &g.lof, tabS.p, g.cl};
+        hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), 0, stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
+        HIPCHECK(hipGetLastError());
+        // marginal right-hand sides (the small-space kernels read pi themselves and write the links)
+        if (!g.paired.empty()) {
+          hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)g.paired.size(), 2, g.maxk > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
+                             b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, g.d_paired.p, b.d_wd.p);
+          HIPCHECK(hipGetLastError());
+        }
+        hipLaunchKernelGGL((k_fill_e0<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p, rhsS.p, g.d_pats.p);
+        HIPCHECK(hipGetLastError());
+        launch_diag(b.d_dS.p, g.d_map.p, tG, nullptr, lidgS.p, nullptr, KD_LIDG);
+        solve(false, LG, pS.p, lidgS.p, rhsS.p, 0, nullptr);
+        hipLaunchKernelGGL((k_seeds<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p,
+                           d_par.p, pS.p, seedS.p, lp.p, g.d_pats.p);
+        HIPCHECK(hipGetLastError());
+      };
+      auto staged_adj = [&](const Staged& g) {
+        if (g.empty()) return;
+        const int tG = (int)g.map.size();
+        const PList LG{b.d_dS.p, g.d_map.p, tG, g.maxk, b.vecS, g.d_lmap.p, &g.lof, tabS.p, g.cl};
+        solve(true, LG, qS.p, lidgS.p, nullptr, 1, seedS.p);
+        launch_grad_rows(b.d_dS.p, (int)g.probs.size(), g.maxk, nullptr, pS.p, qS.p, GS.p, GK_S, g.d_grc);
+        if (g.kind2) {
+          hipLaunchKernelGGL((k_bit_marg<T>), dim3(tG), dim3(BLOCK), 0, stream, b.d_dS.p, g.d_map.p, d_par.p, pS.p, qS.p, bmS.p);
+          HIPCHECK(hipGetLastError());
+        }
+      };
+      time_kernels = force_timing || b.vecJ + b.vecS >= (1ll << 26);
       const long long gjs = (long long)nJ * N * N;
       GJ.p = zarena.p;
       DJ.p = GJ.p + up4(3 * gjs);
@@ -1426,18 +1483,33 @@ struct Engine : EngineBase {
       prep(b.d_dJ.p, nJ, tabJ.p, true, b.maxkcJ);                    // (first: the head of the critical chain)
       // the staged kernels add into their problems' gradient rows; the small-space kernels of the other patients store
       // theirs: cleared before either runs
-      if (staged && grad) {
-        zero(GS.p, (long long)nS * N * N);
-        if (b.g_kind2) zero(bmS.p, (long long)nS * 64);
+      if (staged) {
+        if (grad) {
+          zero(GS.p, (long long)nS * N * N);
+          if (kind2g) zero(bmS.p, (long long)nS * 64);
+        }
+        zero(rhsS.p, b.vecS);
+      }
+      // staged patients that are their own problem: a side stream of their own from here to the assembly (a timed
+      // evaluation keeps them on the main stream - events are recorded there)
+      bool own_forked = false;
+      if (!b.stg[0].empty() && !time_kernels) {
+        HIPCHECK(hipEventRecord(ev_fork[2], stream));
+        HIPCHECK(hipStreamWaitEvent(side[2], ev_fork[2], 0));
+        hipStream_t keep = stream;
+        stream = side[2]; cur_lane = 1;
+        try {
+          staged_fwd(b.stg[0]);
+          if (grad) staged_adj(b.stg[0]);
+        } catch (...) { stream = keep; cur_lane = 0; throw; }
+        stream = keep; cur_lane = 0;
+        HIPCHECK(hipEventRecord(ev_join[2], side[2]));
+        own_forked = true;
       }
       // patients that are their own single-tumour problem need nothing of the joint path: their small-space kernels
       // run on a side stream from here on, next to the joint forward solve (whose launch is issued first - it is the
       // critical chain); the assembly waits for them
       if (fused_small) small_fork(0);
-      if (staged) {                                          // (k_spatient builds its own tables in LDS)
-        hipLaunchKernelGGL((k_prep<T, false>), dim3(nGp), dim3(BLOCK), 0, stream, b.d_dS.p, d_par.p, tabS.p, b.d_gprobs.p);
-        HIPCHECK(hipGetLastError());
-      }
       // The tile solver skips dead tiles and its consumers read them: those parts of pi / q_J must hold zeros - the vectors
       // of the tile route lie behind offT and are cleared once per batch.  The window and per-patient kernels never let a
       // value of a dead tile into arithmetic (they are only ever loaded behind a per-state select): no clearing, which
@@ -1458,42 +1530,19 @@ struct Engine : EngineBase {
         psolve(false, b, pi.p, 2);
       }
       if (fused_small) small_classes(b, 0, grad);
-      // 3 marginal right-hand sides of the staged problems (the small-space kernels read pi themselves and write the links)
-      if (staged) {
-        zero(rhsS.p, b.vecS);
-        if (!b.gpaired.empty()) {
-          hipLaunchKernelGGL((k_gather_marg<T>), dim3((unsigned)b.gpaired.size(), 2, b.maxkG > 10 ? 8 : 1), dim3(BLOCK), 0, stream,
-                             b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, b.d_gpaired.p, b.d_wd.p);
-          HIPCHECK(hipGetLastError());
-        }
-      }
       if (fused_small) small_classes(b, 1, grad);
-      if (staged) {
-        hipLaunchKernelGGL((k_fill_e0<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p, rhsS.p, b.d_gpats.p);
-        HIPCHECK(hipGetLastError());
-        // 4 single-tumour spaces
-        launch_diag(b.d_dS.p, b.d_mapG.p, tG, nullptr, lidgS.p, nullptr, KD_LIDG);
-        solve(false, LG, pS.p, lidgS.p, rhsS.p, 0, nullptr);
-        hipLaunchKernelGGL((k_seeds<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p,
-                           d_par.p, pS.p, seedS.p, lp.p, b.d_gpats.p);
-        HIPCHECK(hipGetLastError());
-      }
+      // 3-4 the staged single-tumour problems (the paired rows' after the joint forward solve)
+      if (!own_forked) staged_fwd(b.stg[0]);
+      staged_fwd(b.stg[1]);
       if (grad) {
-        if (staged) {
-          solve(true, LG, qS.p, lidgS.p, nullptr, 1, seedS.p);
-          launch_grad_rows(b.d_dS.p, nGp, b.maxkG, nullptr, pS.p, qS.p, GS.p, GK_S, b.d_grcG);
-          if (b.g_kind2) {
-            hipLaunchKernelGGL((k_bit_marg<T>), dim3(tG), dim3(BLOCK), 0, stream, b.d_dS.p, b.d_mapG.p, d_par.p,
-                               pS.p, qS.p, bmS.p);
-            HIPCHECK(hipGetLastError());
-          }
-        }
+        if (!own_forked) staged_adj(b.stg[0]);
+        staged_adj(b.stg[1]);
         if (nJ) {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
-          for (int part = 0; part < 2 && !b.gpaired.empty(); ++part) {
-            hipLaunchKernelGGL((k_scatter_marg<T>), dim3((unsigned)b.gpaired.size()), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
-                               b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part, b.d_gpaired.p);
+          for (int part = 0; part < 2 && !b.stg[1].paired.empty(); ++part) {
+            hipLaunchKernelGGL((k_scatter_marg<T>), dim3((unsigned)b.stg[1].paired.size()), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
+                               b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part, b.stg[1].d_paired.p);
             HIPCHECK(hipGetLastError());
           }
           if (use_jacobi) solve(true, LJ, qJ.p, lidgJ.p, rhsJ.p, 0, nullptr);
@@ -1533,6 +1582,7 @@ struct Engine : EngineBase {
         // 7 assembly
       }
       if (fused_small) small_join(0);
+      if (own_forked) HIPCHECK(hipStreamWaitEvent(stream, ev_join[2], 0));
       const AsmArgs<T> aa{b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, GS.p, GJ.p, gjs, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, N,
                           grad ? 1 : 0};
       const int nelem = grad ? st : 1;
@@ -1570,6 +1620,11 @@ struct Engine : EngineBase {
       std::memcpy(host_sums, hs.data(), hs.size() * sizeof(double));
       finish_eval(t0);
     }
+  }
+  void reset_counters() {                              // (what RCCL said about the communicator stays)
+    const int r = cnt.comm_ranks, k = cnt.comm_rank;
+    cnt = mmhn_counters{};
+    cnt.comm_ranks = r; cnt.comm_rank = k;
   }
   void finish_eval(std::chrono::steady_clock::time_point t0) {
     collect_events();
@@ -1648,10 +1703,21 @@ struct Engine : EngineBase {
     comm_destroy();
     RCCLCHECK(rccl().CommInitRank(&comm, nranks, id, rank));
     comm_rank = rank; comm_size = nranks;
+    // what RCCL itself says about the communicator (mmhn_get_counters: the bench line's proof that it spans the ranks)
+    int cnt_ = 0, rk_ = -1;
+    RCCLCHECK(rccl().CommCount(comm, &cnt_));
+    RCCLCHECK(rccl().CommUserRank(comm, &rk_));
+    if (cnt_ != nranks || rk_ != rank) {
+      comm_destroy();
+      throw Fail{"comm_init: RCCL reports " + std::to_string(cnt_) + " ranks / rank " + std::to_string(rk_) + ", asked for " +
+                 std::to_string(nranks) + " / " + std::to_string(rank)};
+    }
+    cnt.comm_ranks = cnt_; cnt.comm_rank = rk_;
   }
   void comm_destroy() {
     if (comm) { (void)rccl().CommDestroy(comm); comm = nullptr; }
     comm_rank = 0; comm_size = 1;
+    cnt.comm_ranks = 0; cnt.comm_rank = -1;
   }
 
   // ---------------------------------------------------------------- single-problem primitives (API / tests)
@@ -2502,7 +2568,7 @@ int mmhn_abi_version(void) { return MMHN_ABI_VERSION; }
 int mmhn_reset_counters(mmhn_handle h) {
   API_BEGIN
   GUARD(h);
-  DISPATCH(h, cnt = mmhn_counters{});
+  DISPATCH(h, reset_counters());
   API_END
 }
 

@@ -43,6 +43,11 @@ struct CoopCtl {
   unsigned abort;    // != 0: a spin timed out
   unsigned pad[7];
 };
+#ifndef MMHN_CS_WPE
+#define MMHN_CS_WPE TSB_WPE      // waves per SIMD k_csolve's register budget is sized for (8: two workgroups per CU, 4: one)
+#endif
+constexpr int CS_WPE = MMHN_CS_WPE;
+constexpr int CS_WG_PER_CU = CS_WPE * 256 / TSB;
 constexpr unsigned COOP_SPIN_LIMIT = 1u << 22;   // polls of one wait before it gives up (seconds; a healthy wait is microseconds)
 
 template <typename T>
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_tsolve(const Desc* __restrict_
 //   ctl->head[slot]: queue head;  h_abort: the pinned host copy of ctl->abort.
 // ------------------------------------------------------------------------------------
 template <typename T, bool TR, bool LIDGV>
-__global__ __launch_bounds__(TSB, TSB_WPE) void k_csolve(const Desc* __restrict__ descs,
+__global__ __launch_bounds__(TSB, CS_WPE) void k_csolve(const Desc* __restrict__ descs,
                                                 const CItem* __restrict__ items, const int* __restrict__ deps, int nitems,
                                                 unsigned* flags, unsigned epoch, CoopCtl* ctl, int slot, unsigned* h_abort,
                                                 T* y, const T* __restrict__ lidg,
@@ -346,16 +351,29 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_csolve(const Desc* __restrict_
           }
           __builtin_amdgcn_s_sleep(2);
         }
+#ifndef MMHN_CS_NOACQ   // (timing-only ablation: wrong results)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE acquire after the match: drops this CU's stale lines
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... and is complete before the barrier lets the loads go
+#endif
       }
       __syncthreads();
     };
+#ifdef MMHN_CS_PLAIN    // variant: plain stores + ONE agent-scope release (L2 write-back) instead of write-through stores
+    tsolve_tile<T, TR, LIDGV, false>(smem, descs, ci.prob, ci.H, y, lidg, rhs, rhs_mode, scal, perm, maxk, tab, links, qS, wait);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(flags + it, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
     tsolve_tile<T, TR, LIDGV, true>(smem, descs, ci.prob, ci.H, y, lidg, rhs, rhs_mode, scal, perm, maxk, tab, links, qS, wait);
     // publish: every storing wave drains its write-through stores, the workgroup meets, one lane raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + it, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   }
 }
 

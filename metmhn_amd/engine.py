@@ -328,7 +328,7 @@ class Engine:
     def counters(self):
         c = _lib.Counters()
         _lib.check(self.lib.mmhn_get_counters(self.h, C.byref(c)))
-        out = {"eval_ms": c.eval_ms, "evals": c.evals}
+        out = {"eval_ms": c.eval_ms, "evals": c.evals, "comm_ranks": int(c.comm_ranks), "comm_rank": int(c.comm_rank)}
         for i, name in enumerate(_lib.KERNEL_CLASSES):
             k = c.kernel[i]
             out[name] = {"ms": k.ms, "launches": k.launches, "alg_bytes": k.alg_bytes}

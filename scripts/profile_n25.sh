@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=$1
-ARGS="--config 4 --gpus 1 --steps 1 --warmup 0 --no-cpu --no-extras"
+ARGS="--config 4 --gpus 1 --steps 1 --warmup 0 --no-cpu --no-extras --min-seconds 0"
 cd /tmp
 rm -rf $R/gpurun_out/prof_${tag}_n25 /tmp/pmc_n25_f /tmp/pmc_n25_w
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_n25 -- python3 $R/bench.py $ARGS > $R/gpurun_out/${tag}_n25_profiled_line.json 2> /dev/null

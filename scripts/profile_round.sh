@@ -14,7 +14,7 @@ cd /tmp
 rm -rf $R/gpurun_out/prof_${tag}_kv $R/gpurun_out/prof_${tag}_luad $R/gpurun_out/${tag}_pmc
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_kv -- python3 $R/scripts/kv_only.py > $R/gpurun_out/${tag}_kv.log 2>&1
 cp $R/gpurun_out/prof_${tag}_kv/*/*kernel_stats.csv $R/gpurun_out/${tag}_kronvec_kernel_stats.csv
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_luad -- python3 $R/bench.py --workload luad --steps 20 --warmup 3 --no-cpu --no-extras > $R/gpurun_out/${tag}_luad_line.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_luad -- python3 $R/bench.py --workload luad --steps 20 --warmup 3 --min-seconds 0 --no-cpu --no-extras > $R/gpurun_out/${tag}_luad_line.json 2> /dev/null
 cp $R/gpurun_out/prof_${tag}_luad/*/*kernel_stats.csv $R/gpurun_out/${tag}_luad_kernel_stats.csv
 mkdir -p $R/gpurun_out/${tag}_pmc
 for pass in "eval_f FETCH_SIZE eval_only.py 5000" "eval_w WRITE_SIZE eval_only.py 5000" "kv_f FETCH_SIZE kv_only.py" "kv_w WRITE_SIZE kv_only.py" \

@@ -789,6 +789,47 @@ def test_luad_reduced_anchor(golden):
     np.testing.assert_allclose(gr, g["indep_reg_grad"], rtol=1e-7, atol=1e-10)
 
 
+def test_luad28_real_workload(monkeypatch, golden):
+    """The cohort examples/analysis.py of the reference really fits (`muts = list(dat.columns[1:-4])`,
+    examples/analysis.py:55): ALL 28 events, 4 852 x 59 int8, 453 paired rows with k = 1 .. 21 (110 rows with k >= 13 carry 99 % of
+    the work, class splits like (8, 9), (9, 10), (11, 8)), single-tumour spaces of up to 17 bits - a heterogeneous cohort: every
+    joint problem on its own route (per-problem dispatch), the tiles of the large ones in ONE cooperative launch with several
+    workgroups per patient (csrc/tsolve.h: k_csolve), patients with a single-tumour space of more than a tile on the staged
+    kernels next to the small-space path.  Fixture: tests/tools/make_golden_luad.py luad28 (values by oracle/metmhn_ref.c /
+    metmhn_fast.c, which are pinned to the reference elsewhere) at indep(dat) and at the reference's published parameters
+    (results/luad/luad_g14_cv_20muts_8cnvs.csv).  1e-9 on the score, 1e-7 on the gradients; three dispatches: the default,
+    level-by-level launches instead of the cooperative one (MMHN_COOP=0), and every window / multi-tile problem forced onto its
+    per-patient kernel (MMHN_PSOLVE_MIN=1) with the solution buffers NaN-poisoned."""
+    import os
+    if not os.path.exists(os.path.join(GOLDEN, "luad28.npz")):
+        pytest.skip("luad28.npz not generated")
+    from metmhn_amd import Engine, Utilityfunctions as U
+    g = golden("luad28")
+    dat = g["dat"]
+    assert dat.shape == (4852, 59) and list(np.bincount(dat[:, -1])) == [595, 1677, 2127, 453]
+    th, dp, dm = U.indep(dat)
+    np.testing.assert_allclose(th, g["indep_theta"], rtol=1e-12)
+    pm = float(g["perc_met"])
+    for env in ({}, {"MMHN_COOP": "0"}, {"MMHN_PSOLVE_MIN": "1", "MMHN_POISON": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        e = Engine(28)
+        e.set_cohort(dat)
+        for pt in ("indep", "fit"):
+            lt, a, b = g[pt + "_theta"], g[pt + "_dp"], g[pt + "_dm"]
+            s, G, ga, gb = e.score_and_grad(lt, a, b, pm)
+            np.testing.assert_allclose(s, g[pt + "_score"], rtol=1e-9, err_msg=f"{pt} {env}")
+            np.testing.assert_allclose(G, g[pt + "_d_th"], rtol=1e-7, atol=1e-10, err_msg=f"{pt} {env}")
+            np.testing.assert_allclose(ga, g[pt + "_d_dp"], rtol=1e-7, atol=1e-10, err_msg=f"{pt} {env}")
+            np.testing.assert_allclose(gb, g[pt + "_d_dm"], rtol=1e-7, atol=1e-10, err_msg=f"{pt} {env}")
+            np.testing.assert_allclose(float(e.score(lt, a, b, pm)), g[pt + "_score"], rtol=1e-9)
+        lp = e.patient_grads(g["fit_theta"], g["fit_dp"], g["fit_dm"])[0]
+        np.testing.assert_allclose(lp, g["fit_lp"], rtol=1e-9, atol=1e-11, err_msg=f"per-patient log-probs {env}")
+        e.close()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
 def test_luad_fit_reaches_published_objective(golden):
     """learn_mhn from indep(dat) with the reference's own LUAD settings (perc_met 0.2, lambda 1e-3,
     ftol 1e-5; examples/data_analysis.ipynb cell 14).  The engine's objective equals the reference's at the published

@@ -225,6 +225,40 @@ def test_luad_reduced_anchor_cpu(golden):
     np.testing.assert_allclose(np.linalg.norm(gi["indep_d_dm"]), 0.03620795819315152, rtol=1e-12)
 
 
+def test_luad28_fixture_cpu(golden):
+    """The 28-event LUAD cohort (examples/analysis.py:55; tests/tools/make_golden_luad.py luad28): the fixture's values come
+    from oracle/metmhn_ref.c - here the second C port (metmhn_fast.c, gather formulation) reproduces the stored per-patient
+    log-probabilities of all 453 paired rows (k up to 21) at both parameter points, the NumPy restatement (reference pass
+    structure, oracle/metmhn_oracle.py) those of the unpaired rows and of the small paired ones it finishes in seconds, and the
+    cohort formula the stored score."""
+    from oracle import cref
+    g = golden("luad28")
+    dat = g["dat"]
+    assert dat.shape == (4852, 59) and list(np.bincount(dat[:, -1])) == [595, 1677, 2127, 453]
+    paired = np.flatnonzero(dat[:, -1] == 3)
+    assert np.array_equal(paired, g["paired_rows"])
+    for pre in ("indep_", "fit_"):
+        lt, dp, dm = g[pre + "theta"], g[pre + "dp"], g[pre + "dm"]
+        lpf, gf, af, bf = cref.fast_patients(lt, dp, dm, dat[paired])
+        np.testing.assert_allclose(lpf, g[pre + "lp"][paired], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(np.sqrt((gf ** 2).sum((1, 2)) + (af ** 2).sum(1) + (bf ** 2).sum(1)), g[pre + "g_fast_norm"], rtol=1e-10)
+    # NumPy restatement on a sample: every 40th row with at most 9 active slots
+    k = dat[:, :-2].sum(1)
+    rows = [r for r in range(0, dat.shape[0], 40) if k[r] <= 9]
+    lt, dp, dm = g["fit_theta"], g["fit_dp"], g["fit_dm"]
+    for r in rows:
+        one = dat[r:r + 1]
+        s = float(O.score(lt, dp, dm, one, 0.5))
+        np.testing.assert_allclose(s, g["fit_lp"][r], rtol=1e-10, atol=1e-12, err_msg=f"row {r}")
+    em = dat[:, -1] != 0
+    pm = float(g["perc_met"])
+    n_em = float(dat[:, -3].sum()); n_nm = dat.shape[0] - n_em
+    w = pm * n_nm / ((1 - pm) * n_em)
+    for pre in ("indep_", "fit_"):
+        lp = g[pre + "lp"]
+        np.testing.assert_allclose((w * lp[em].sum() + lp[~em].sum()) / (w * n_em + n_nm), g[pre + "score"], rtol=1e-13)
+
+
 def test_window_schedule_model():
     """oracle/wschedule.py: the scalar model of k_wsolve's schedule (lanes skewed by whole register windows, waves by
     blocks, external bits from the thread's own earlier output) solves the Kronecker-sum system exactly, forward and
