@@ -442,6 +442,17 @@ def main():
         rf_marg = kern("pclass", f"{'k_wclass' if wsolve else 'k_pclass'}<{T}> (class marginals of pi (x) q)", "pi and q_J read once (seeded halves)")
         rf_other = kern("other_solve", "k_tsolve / k_sweep (level-by-level solves of the marginal single-tumour problems)",
                         "per tile: solution written once (+ dense rhs / lidg vector reads)")
+        # the patient shards: rows and LPT cost (2^k (k + 1), distributed.patient_cost) per rank
+        from metmhn_amd import distributed as D
+        shard = None
+        try:
+            parts = D.shard_rows(dat, world) if world > 1 else [np.arange(dat.shape[0])]
+            cost = D.patient_cost(dat)
+            loads = [float(cost[p_].sum()) for p_ in parts]
+            shard = {"rows_per_rank": [int(len(p_)) for p_ in parts], "cost_per_rank": loads,
+                     "cost_imbalance_max_over_mean": max(loads) / (sum(loads) / len(loads)) if sum(loads) > 0 else 1.0}
+        except Exception as exc:
+            shard = {"error": repr(exc)}
         live_bytes = (cnt["psolve_fwd"]["alg_bytes"] / max(cnt["psolve_fwd"]["launches"], 1)) if rf_fwd else None
         dominant = rf_fwd or rf_other or {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None}
         out = {
@@ -453,7 +464,7 @@ def main():
             "config": {"workload": wl_name, "patients_total": int(dat.shape[0]), "perc_met": perc_met, "penalty": "symmetric_penal 1e-3",
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
-                       "rccl_ranks": cnt.get("comm_ranks", 0), "rccl_rank": cnt.get("comm_rank", -1),
+                       "rccl_ranks": cnt.get("comm_ranks", 0), "rccl_rank": cnt.get("comm_rank", -1), "shards": shard,
                        "solver": os.environ.get("MMHN_SOLVER", "substitution (k_wsolve: window layout, chains of patients; k_tsolve for the marginals)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
             # dominant kernel of the timed step

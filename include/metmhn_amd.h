@@ -73,6 +73,12 @@ int mmhn_cohort_sums_end(mmhn_handle h, double* sums);
 int mmhn_cohort_wsums_begin(mmhn_handle h, const double* log_theta, const double* log_d_p,
                             const double* log_d_m, int with_grad, double w);
 int mmhn_cohort_wsums_end(mmhn_handle h, double* wsums);
+/* One more double riding in the SAME all-reduce as the wsums buffer (ABI 5): the value set here travels with the NEXT
+ * mmhn_cohort_wsums_begin, is summed over the ranks of the communicator, and is read back after its _end.  The Python host
+ * uses it for the "this rank's cohort array was edited in place" bit of its layout cache, which used to be a second
+ * collective per evaluation (metmhn_amd/regularized_optimization.py: _result). */
+int mmhn_set_reduce_flag(mmhn_handle h, double value);
+int mmhn_get_reduce_flag(mmhn_handle h, double* summed);
 /* per-patient results of the current cohort (tests): lp[n_pat], and if non-NULL
  * d_theta[n_pat][N*N], d_dp[n_pat][N], d_dm[n_pat][N]  (ssr._g_coupled_*, _grad_*_obs) */
 int mmhn_patient_grads(mmhn_handle h, const double* log_theta, const double* log_d_p,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mmhn_cohort_sums_end": [C.c_void_p, f64p],
     "mmhn_cohort_wsums_begin": [C.c_void_p, f64p, f64p, f64p, C.c_int, C.c_double],
     "mmhn_cohort_wsums_end": [C.c_void_p, f64p],
+    "mmhn_set_reduce_flag": [C.c_void_p, C.c_double],
+    "mmhn_get_reduce_flag": [C.c_void_p, f64p],
     "mmhn_patient_grads": [C.c_void_p, f64p, f64p, f64p, f64p, f64p, f64p, f64p],
     "mmhn_kronvec": [C.c_void_p, f64p, i8p, f64p, f64p, C.c_int, C.c_int],
     "mmhn_kronvec_batched": [C.c_void_p, f64p, i8p, C.c_int64, f64p, f64p, C.c_int, C.c_int],

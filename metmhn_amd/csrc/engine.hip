@@ -401,8 +401,9 @@ __global__ void k_pack_sums(const double* __restrict__ sums, int N, double n_em,
 // sums[2][stride] -> the pre-combined buffer of mmhn_cohort_wsums: [w s_EM + s_NM, w G_EM + G_NM, w p_EM + p_NM, w m_EM]
 // (regularized_optimization.py:256-266 without the division by n_full): 1 + N^2 + 2 N doubles, the all-reduce
 // payload of SURVEY 8e - the weight w only needs the GLOBAL counts, which every rank knows when the cohort is set
-__global__ void k_pack_wsums(const double* __restrict__ sums, int N, double w, double* __restrict__ o) {
+__global__ void k_pack_wsums(const double* __restrict__ sums, int N, double w, double* __restrict__ o, double flag) {
   const int st = 1 + N * N + 2 * N, NN = N * N;
+  if (blockIdx.x == 0 && threadIdx.x == 0) o[st] = flag;              // (mmhn_set_reduce_flag: rides in the same all-reduce)
   const double* em = sums;
   const double* nm = sums + st;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < st; e += gridDim.x * blockDim.x)
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_parts_pack(const double* __res
                                                              double* sums, int mode, int N, double a, double b,
                                                              double* __restrict__ o) {
   const int e = blockIdx.x * BLOCK + threadIdx.x;
+  if (e == 0 && mode == 2) o[stride] = b;                             // (mode 2: b = the reduce flag, behind the buffer)
   if (e >= stride) return;
   double em = sums[e], nm = sums[stride + e];
   if (e < nelem) {
@@ -504,6 +506,7 @@ struct Engine : EngineBase {
                                 // follows MMHN_PSOLVE_MIN when only that one is set)
   bool force_timing = false;    // MMHN_TIME_KERNELS=1: HIP events around the solve / class-marginal launches of every batch (bench
                                 // breakdowns of small cohorts; an event pair costs the host ~10 us)
+  int pcl_per = 16;             // MMHN_PCL_PER: tiles of a class pass per work item of k_pclass
   int coop_wgs = 0;             // MMHN_COOP_WGS: workgroups of a cooperative launch (default: two per CU)
   bool coop = true;             // MMHN_COOP=0: tile solves as one launch per level (k_tsolve) instead of one cooperative launch
   // cooperative launches (tsolve.h): queue heads + abort word, the flags of the tiles (value = epoch of the launch that
@@ -565,6 +568,7 @@ struct Engine : EngineBase {
       if (const char* pm = std::getenv("MMHN_COOP")) coop = std::atoi(pm) != 0;
       if (const char* pm = std::getenv("MMHN_TIME_KERNELS")) force_timing = std::atoi(pm) != 0;
       if (const char* pm = std::getenv("MMHN_COOP_WGS")) coop_wgs = std::atoi(pm);
+      if (const char* pm = std::getenv("MMHN_PCL_PER")) pcl_per = std::max(1, std::atoi(pm));
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PAIR_SMALL")) pair_small = std::atoi(sp) != 0;
@@ -990,6 +994,7 @@ struct Engine : EngineBase {
     long long pat_target = 0;
     {
       double total = 0;
+      long long npJ = 0;
       for (long long r = 0; r < np; ++r) {
         const int8_t* row = dat.data() + r * nc;
         int kp = 0, km = 0, ke = 0;
@@ -997,6 +1002,7 @@ struct Engine : EngineBase {
         const int type = row[nc - 1];
         double el = 0;
         if (type == 3) {
+          ++npJ;
           el = (use_jacobi || wsolve_mode == 2 ? 4.0 : 2.0) * std::ldexp(1.0, kp + km + 1) + 4.0 * (std::ldexp(1.0, km + 1) + std::ldexp(1.0, kp + 1)) +
                (kp + 1) * std::ldexp(1.0, kp) + (km + 1) * std::ldexp(1.0, km) + (ke + 2) * std::ldexp(1.0, ke);
         } else {
@@ -1008,9 +1014,15 @@ struct Engine : EngineBase {
       soft_target = nb > 1 ? total / nb * 1.02 : 0;
       // the per-patient kernels take one patient per CU at a time: a batch of 400 costs two rounds of 256.  Batches of a cut
       // cohort hold a multiple of the CU count (rounded down: more, fuller rounds)
-      if (nb > 1 && np > 0) {
-        const double per_batch = (double)ws_limit / (total / (double)np);
-        if (per_batch >= (double)n_cu) pat_target = (long long)(per_batch / n_cu) * n_cu;
+      if (nb > 1 && npJ > 0) {
+        const double per_batch = (double)ws_limit / (total / (double)npJ);     // paired rows (they are what occupies a CU)
+        if (per_batch >= (double)n_cu) {
+          pat_target = (long long)(per_batch / n_cu) * n_cu;
+          // a remainder too small for the window / per-patient routes would be a batch on the tile route alone: spread the
+          // rows evenly over the same number of batches instead
+          const long long nbt = (npJ + pat_target - 1) / pat_target, rem = npJ - (nbt - 1) * pat_target;
+          if (nbt > 1 && rem < std::max(psolve_min, wsolve_min)) pat_target = (npJ + nbt - 1) / nbt;
+        }
       }
     }
     std::vector<int8_t> st(2 * n + 2);
@@ -1067,7 +1079,7 @@ struct Engine : EngineBase {
       const size_t need = footprint(cur.vecJ + nvJ, cur.vecS + nvS, cur.asize + (hasJ ? a_size(dj) : 0), cur.tabJ + cur.tabS + ntab,
                                     cur.dJ.size() + (hasJ ? 1 : 0), cur.dS.size() + (has0 ? 1 : 0) + (has1 ? 1 : 0), cur.pats.size() + 1);
       const size_t have = footprint(cur.vecJ, cur.vecS, cur.asize, cur.tabJ + cur.tabS, cur.dJ.size(), cur.dS.size(), cur.pats.size());
-      if (!cur.pats.empty() && (need > ws_limit || (pat_target > 0 ? (long long)cur.pats.size() >= pat_target
+      if (!cur.pats.empty() && (need > ws_limit || (pat_target > 0 ? (hasJ && (long long)cur.dJ.size() >= pat_target)
                                                                          : (soft_target > 0 && (double)have >= soft_target)))) flush();
       if (hasJ) {
         dj.off = cur.vecJ; dj.aoff = cur.asize; dj.toff = cur.tabJ; cur.tabJ += table_size(dj);
@@ -1231,7 +1243,7 @@ struct Engine : EngineBase {
           for (int c = 0; c < 2; ++c) {
             const int kc = c == 0 ? kP : kM, kf = c == 0 ? kM : kP;
             const int no = pclass_outer_bits(kc, kf), nh = kc > PCA ? kc - PCA : 0;
-            const int per = std::max(1, 16 >> nh);                            // tiles per item: (2^nh class blocks) x (per settings)
+            const int per = std::max(1, pcl_per >> nh);                       // tiles per item: (2^nh class blocks) x (per settings)
             for (int o0 = 0; o0 < (1 << no); o0 += per) b.pcl.push_back(int4{pj, c, o0, std::min(o0 + per, 1 << no)});
           }
         }
@@ -1439,7 +1451,6 @@ struct Engine : EngineBase {
       const int tJ = (int)b.mapJ.size();
       const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};       // (Jacobi solver only)
       const bool fused_small = b.has_small, staged = !b.stg[0].empty() || !b.stg[1].empty();
-      const bool kind2g = b.stg[0].kind2 || b.stg[1].kind2;
       // the staged kernels of one group of patients (Batch::stg): forward part (tables, right-hand sides, 1/diag, forward solve,
       // scores and adjoint seeds) and gradient part (adjoint solve, gradient rows, observation-rate marginals)
       auto staged_fwd = [&](const Staged& g) {
@@ -1447,6 +1458,9 @@ struct Engine : EngineBase {
         const int nG = (int)g.pats.size(), tG = (int)g.map.size();
         // (Jacobi / MMHN_SMALL=0: the group is every single-tumour problem, so that vec = every single-tumour vector)
         const PList LG{b.d_dS.p, g.d_map.p, tG, g.maxk, b.vecS, g.d_lmap.p, &g.lof, tabS.p, g.cl};
+        // (the group's accumulators cleared, the e_0 right-hand sides written: before anything of the group runs)
+        hipLaunchKernelGGL((k_staged_init<T>), dim3(nG), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dS.p, rhsS.p, GS.p, bmS.p, N, grad ? 1 : 0, g.d_pats.p);
+        HIPCHECK(hipGetLastError());
         hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), 0, stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
         HIPCHECK(hipGetLastError());
         // marginal right-hand sides (the small-space kernels read pi themselves and write the links)
@@ -1455,8 +1469,6 @@ struct Engine : EngineBase {
                              b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, pi.p, rhsS.p, links.p, g.d_paired.p, b.d_wd.p);
           HIPCHECK(hipGetLastError());
         }
-        hipLaunchKernelGGL((k_fill_e0<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p, rhsS.p, g.d_pats.p);
-        HIPCHECK(hipGetLastError());
         launch_diag(b.d_dS.p, g.d_map.p, tG, nullptr, lidgS.p, nullptr, KD_LIDG);
         solve(false, LG, pS.p, lidgS.p, rhsS.p, 0, nullptr);
         hipLaunchKernelGGL((k_seeds<T>), dim3((nG + 255) / 256), dim3(256), 0, stream, b.d_pats.p, nG, b.d_dS.p,
@@ -1481,15 +1493,6 @@ struct Engine : EngineBase {
       Abuf.p = DJ.p + up4(3ll * nJ * N);
       if (grad && nJ && !(head_done && &b == &batches.front())) zero(zarena.p, zarena_elems(nJ, b.asize, N));
       prep(b.d_dJ.p, nJ, tabJ.p, true, b.maxkcJ);                    // (first: the head of the critical chain)
-      // the staged kernels add into their problems' gradient rows; the small-space kernels of the other patients store
-      // theirs: cleared before either runs
-      if (staged) {
-        if (grad) {
-          zero(GS.p, (long long)nS * N * N);
-          if (kind2g) zero(bmS.p, (long long)nS * 64);
-        }
-        zero(rhsS.p, b.vecS);
-      }
       // staged patients that are their own problem: a side stream of their own from here to the assembly (a timed
       // evaluation keeps them on the main stream - events are recorded there)
       bool own_forked = false;
@@ -1648,6 +1651,8 @@ struct Engine : EngineBase {
   // w_combined (optional): pack w * EM + NM on the device (k_pack_wsums) - 1 + N^2 + 2N doubles travel instead of
   // 4 + 2 N^2 + 3 N
   int sums_len = 0;                                           // doubles of the pending result
+  double reduce_flag = 0.0, reduce_flag_sum = 0.0;            // mmhn_set_reduce_flag / mmhn_get_reduce_flag
+  bool flag_pending = false;
   void cohort_sums_begin(const double* lt, const double* ldp, const double* ldm, bool grad, const double* w_combined = nullptr) {
     REQUIRE(!sums_pending, "mmhn_cohort_sums_begin: the previous evaluation has not been collected");
     sums_t0 = std::chrono::steady_clock::now();
@@ -1662,17 +1667,20 @@ struct Engine : EngineBase {
     // all-reduce works on device memory and the copy engine brings its result down
     double* packed = (zero_copy && !comm) ? h_abi_dev : abi_sums.p;
     pack_mode = w_combined ? 2 : 1;
-    pack_a = w_combined ? *w_combined : (double)n_em; pack_b = (double)n_pat; pack_dst = packed;
+    pack_a = w_combined ? *w_combined : (double)n_em; pack_b = w_combined ? reduce_flag : (double)n_pat; pack_dst = packed;
     packed_in_eval = false;
     struct Unset { int& m; ~Unset() { m = 0; } } unset{pack_mode};
     evaluate(lt, ldp, ldm, grad, nullptr, nullptr);
     if (!packed_in_eval) {                                 // (no batch: an empty cohort)
-      if (w_combined) hipLaunchKernelGGL(k_pack_wsums, dim3(2), dim3(256), 0, stream, sums.p, N, *w_combined, packed);
+      if (w_combined) hipLaunchKernelGGL(k_pack_wsums, dim3(2), dim3(256), 0, stream, sums.p, N, *w_combined, packed, reduce_flag);
       else hipLaunchKernelGGL(k_pack_sums, dim3(2), dim3(256), 0, stream, sums.p, N, n_em, (double)n_pat, packed);
       HIPCHECK(hipGetLastError());
     }
-    if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)total, ncclFloat64, ncclSum, comm, stream));
-    if (packed == abi_sums.p) HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+    const int moved = total + (w_combined ? 1 : 0);            // (the reduce flag rides behind the pre-combined buffer)
+    if (comm) RCCLCHECK(rccl().AllReduce(abi_sums.p, abi_sums.p, (size_t)moved, ncclFloat64, ncclSum, comm, stream));
+    if (packed == abi_sums.p) HIPCHECK(hipMemcpyAsync(h_abi, abi_sums.p, moved * sizeof(double), hipMemcpyDeviceToHost, stream));
+    flag_pending = w_combined != nullptr;
+    reduce_flag = 0.0;
     sums_issued = std::chrono::steady_clock::now();
     sums_pending = true;
     sums_len = total;
@@ -1684,6 +1692,7 @@ struct Engine : EngineBase {
     HIPCHECK(hipStreamSynchronize(stream));
     check_abort();
     std::memcpy(o, h_abi, (size_t)sums_len * sizeof(double));
+    reduce_flag_sum = flag_pending ? h_abi[sums_len] : 0.0;
     static const bool trace_host = std::getenv("MMHN_TRACE_HOST") != nullptr;   // diagnostic: host time to issue vs total
     if (trace_host)
       std::fprintf(stderr, "[mmhn] evaluation issued after %.1f us, complete after %.1f us\n",
@@ -2178,6 +2187,22 @@ int mmhn_cohort_wsums_begin(mmhn_handle h, const double* lt, const double* ldp, 
   REQUIRE(lt && ldp && ldm, "null pointer");
   REQUIRE(std::isfinite(w), "w must be finite");
   DISPATCH(h, cohort_sums_begin(lt, ldp, ldm, with_grad != 0, &w));
+  API_END
+}
+
+int mmhn_set_reduce_flag(mmhn_handle h, double value) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(std::isfinite(value), "the flag must be finite");
+  DISPATCH(h, reduce_flag = value);
+  API_END
+}
+int mmhn_get_reduce_flag(mmhn_handle h, double* summed) {
+  API_BEGIN
+  GUARD(h);
+  REQUIRE(summed, "null pointer");
+  if (h->dtype == MMHN_F64) *summed = static_cast<Engine<double>*>(h->impl)->reduce_flag_sum;
+  else *summed = static_cast<Engine<float>*>(h->impl)->reduce_flag_sum;
   API_END
 }
 

@@ -1581,14 +1581,26 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
   if (threadIdx.x == 0) dots[2 * pat + part] = red[0];
 }
 
-// e_0 right-hand sides of the unpaired patients' own single-tumour problems
+// head of the staged single-tumour kernels, one workgroup per staged patient: the e_0 right-hand side of an unpaired
+// patient's own problem (the whole vector is written: nothing else clears it; a paired row's right-hand sides are written by
+// k_gather_marg), and the accumulators the staged kernels add into - the gradient rows (k_grad_rows) and the observation-rate
+// marginals (k_bit_marg) of its problems - cleared.  (The other patients' rows are STORED by the small-space kernels.)
 template <typename T>
-__global__ void k_fill_e0(const PatRec* __restrict__ pats, int npat, const Desc* __restrict__ dS, T* rhsS,
-                          const int* __restrict__ plist) {
-  const int ii = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ii >= npat) return;
-  const PatRec pr = pats[plist ? plist[ii] : ii];
-  if (pr.kind <= 2 && pr.s[0] >= 0) rhsS[dS[pr.s[0]].off] = e0_scale<T>();
+__global__ __launch_bounds__(BLOCK) void k_staged_init(const PatRec* __restrict__ pats, const Desc* __restrict__ dS, T* rhsS,
+                                                       T* GS, T* bmS, int N, int with_grad, const int* __restrict__ plist) {
+  const PatRec pr = pats[plist[blockIdx.x]];
+  for (int part = 0; part < 2; ++part) {
+    const int sp = pr.s[part];
+    if (sp < 0) continue;
+    if (with_grad) {
+      for (int e = threadIdx.x; e < N * N; e += BLOCK) GS[(long long)sp * N * N + e] = T(0);
+      if (threadIdx.x < 64) bmS[(long long)sp * 64 + threadIdx.x] = T(0);
+    }
+    if (pr.kind <= 2 && part == 0) {
+      const long long off = dS[sp].off, V = 1ll << dS[sp].k;
+      for (long long e = threadIdx.x; e < V; e += BLOCK) rhsS[off + e] = e == 0 ? e0_scale<T>() : T(0);
+    }
+  }
 }
 
 // per patient: total marginal score, adjoint seeds 1/score for its single problems, log-prob

@@ -48,7 +48,10 @@ struct CoopCtl {
 #endif
 constexpr int CS_WPE = MMHN_CS_WPE;
 constexpr int CS_WG_PER_CU = CS_WPE * 256 / TSB;
-constexpr unsigned COOP_SPIN_LIMIT = 1u << 22;   // polls of one wait before it gives up (seconds; a healthy wait is microseconds)
+#ifndef MMHN_CS_SLEEP
+#define MMHN_CS_SLEEP 16         // s_sleep argument between two polls of a wait (units of 64 cycles)
+#endif
+constexpr unsigned COOP_SPIN_LIMIT = 1u << 21;   // polls of one wait before it gives up (seconds; a healthy wait is microseconds)
 
 template <typename T>
 __device__ __forceinline__ void store_wt(T* p, T v) {          // write-through store (sc1): leaves the XCD's L2 at once
@@ -75,6 +78,8 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
   T* Ltab = yt + (1 << TB);
   T* Utab = Ltab + maxk * 64;
   const int tid = threadIdx.x;
+  STAMP_DECL;                    // (-DMMHN_STAMPS: scripts/tile_stamps.py)
+  STAMP_START;
   load_desc(&d, descs + prob);
   __syncthreads();
   const int k = d.k;
@@ -155,7 +160,9 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
     }
     __syncthreads();   // pxt lives in the Utab area: done before tile_tables overwrites it
   }
+  STAMP(0);
   tile_tables(d, tab, H, Ltab, Utab, yt);
+  STAMP(1);
 
   const int wave = tid >> 6, lane = tid & 63;
   const uint32_t last = (1u << k) - 1u;
@@ -175,7 +182,9 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
     }
     acc[j] = rv;
   }
+  STAMP(2);
   wait();                                                      // (k_csolve: the tiles read below are complete and visible)
+  STAMP(3);
   for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
     const int c = d.cls[b];
     const bool is_seed = joint && c == CS;
@@ -216,6 +225,7 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
     if (xl < nelem) yt[xl] = acc[j];
   }
   __syncthreads();
+  STAMP(4);
 
   // ---- step B: popcount-ordered substitution inside the tile (a state's level is its popcount)
   const uint32_t pairP = joint ? d.pairP : 0u;
@@ -272,12 +282,19 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
     __syncthreads();
   }
 
+  STAMP(5);
   // ---- step C
   if constexpr (WT) {
     for (uint32_t e = tid; e < nelem; e += TSB) store_wt(y + base + xhi + e, yt[e]);
   } else {
     for (uint32_t e = tid; e < nelem; e += TSB) y[base + xhi + e] = yt[e];
   }
+#ifdef MMHN_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP(6);
+  if (st_on) st_sum[7] += 1;     // tiles
+  if (t == TB) STAMP_FLUSH(TR ? 8 : 0);       // (the full tiles of the large problems only)
+#endif
 }
 
 // one launch per level of tile-index popcount (host: Engine::solve)
@@ -334,22 +351,28 @@ __global__ __launch_bounds__(TSB, CS_WPE) void k_csolve(const Desc* __restrict__
     auto wait = [&]() {
       if (ci.ndep == 0) return;                                // (uniform)
       if (tid < 64) {
+        // one wave polls: lane i its i-th dependency, only until it has seen it done; the abort word every eighth round;
+        // between two rounds the wave sleeps (a few hundred workgroups poll at the same time: the polls are memory traffic
+        // of their own - MI355X_MICROARCH.md "polling-cost")
         const int lane = tid;
-        const unsigned* f = lane < ci.ndep ? flags + deps[ci.dep0 + lane] : &ctl->abort;
+        const unsigned* f = flags + deps[ci.dep0 + (lane < ci.ndep ? lane : 0)];
+        bool done = lane >= ci.ndep;
         unsigned spins = 0;
         for (;;) {
-          const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool ok = lane < ci.ndep ? v == epoch : true;
-          const bool ab = lane >= ci.ndep && v != 0u;
-          if (__all(ok) || __any(ab)) break;
-          if (++spins > COOP_SPIN_LIMIT) {
-            if (lane == 0) {
-              __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(h_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (!done) done = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+          if (__all(done)) break;
+          if ((++spins & 7u) == 0u) {
+            const unsigned ab = __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab != 0u) break;
+            if (spins > COOP_SPIN_LIMIT) {
+              if (lane == 0) {
+                __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(h_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
+              break;
             }
-            break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(MMHN_CS_SLEEP);
         }
 #ifndef MMHN_CS_NOACQ   // (timing-only ablation: wrong results)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // ONE acquire after the match: drops this CU's stale lines

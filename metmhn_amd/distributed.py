@@ -44,6 +44,90 @@ def fold_jobs(n_lambda: int, n_folds: int, rank: int = 0, world_size: int = 1) -
     return jobs[rank::world_size]
 
 
+class CommAbandoned(RuntimeError):
+    """A rank gave up on the collective set-up of the in-library communicator (another rank failed, or it timed out)."""
+
+
+_JOIN_GEN = [0]
+
+
+def collective_init(init_fn, rank: int, world: int, store, timeout: float = 180.0, poll: float = 0.2) -> tuple[bool, str]:
+    """Run `init_fn()` (a blocking collective set-up: ncclCommInitRank) on every rank and decide TOGETHER whether it
+    succeeded, without ever leaving a rank alone in it for long.  Returns (all_ok, first error message).
+
+    Protocol over the torch.distributed key-value store (no collective: a collective would hang on the ranks that are
+    still blocked inside init_fn).  Every call has a generation number (all ranks call in the same order); a rank writes
+    ONE status key  mmhn_comm/<gen>/<rank> = "ok" | "err:<message>" | "abandoned:<why>":
+      * init_fn returns            -> "ok"
+      * init_fn raises             -> "err:..."  (a rank that fails BEFORE entering the set-up - the library is missing, a
+                                      device is gone: the case in which its peers would sit in ncclCommInitRank until the
+                                      timeout - is what the others see within `poll` seconds)
+      * init_fn is still blocked while another rank's key says err / abandoned, or after `timeout` seconds
+                                   -> "abandoned:...", and CommAbandoned is raised: the blocked thread cannot be
+                                      cancelled, so this process is expected to end (the job dies in seconds, not after
+                                      MMHN_COMM_TIMEOUT).
+    Once every rank's key is there: all "ok" -> (True, ""); an "abandoned" anywhere -> CommAbandoned on every rank (a
+    process is about to die: no fallback can be collective); otherwise (errors only, nobody blocked) -> (False, message):
+    the caller's ranks fall back together."""
+    import threading
+    import time
+    gen = _JOIN_GEN[0]
+    _JOIN_GEN[0] += 1
+    res = {}
+
+    def _run():
+        try:
+            init_fn()
+            res["ok"] = True
+        except Exception as exc:                               # noqa: BLE001
+            res["err"] = f"{type(exc).__name__}: {exc}"
+
+    th = threading.Thread(target=_run, daemon=True)
+    th.start()
+    if world == 1 or store is None:
+        th.join(timeout)
+        if th.is_alive():
+            raise CommAbandoned("communicator set-up did not return within the timeout")
+        return bool(res.get("ok")), res.get("err", "")
+    key = lambda r: f"mmhn_comm/{gen}/{r}"                    # noqa: E731
+
+    def peers():
+        out = {}
+        for r in range(world):
+            if r != rank and store.check([key(r)]):
+                out[r] = store.get(key(r)).decode()
+        return out
+
+    t0 = time.monotonic()
+    while True:
+        th.join(poll)
+        if not th.is_alive():
+            break
+        bad = {r: v for r, v in peers().items() if not v.startswith("ok")}
+        if bad:
+            r, v = next(iter(bad.items()))
+            store.set(key(rank), f"abandoned:rank {r} reported {v}")
+            raise CommAbandoned(f"rank {r} failed while this rank was still inside the communicator set-up ({v}); giving up")
+        if time.monotonic() - t0 > timeout:
+            store.set(key(rank), "abandoned:timeout")
+            raise CommAbandoned(f"communicator set-up did not return within {timeout:.0f} s - a rank is missing")
+    mine = "ok" if res.get("ok") else "err:" + res.get("err", "unknown")
+    store.set(key(rank), mine)
+    while True:
+        got = peers()
+        if len(got) == world - 1:
+            break
+        if any(v.startswith("abandoned") for v in got.values()) or time.monotonic() - t0 > timeout:
+            break
+        time.sleep(poll)
+    got[rank] = mine
+    gone = {r: v for r, v in got.items() if v.startswith("abandoned")}
+    if gone or len(got) < world:
+        raise CommAbandoned(f"communicator set-up abandoned by {sorted(gone) or 'a rank that never reported'}: {gone}")
+    errs = [f"rank {r}: {v[4:]}" for r, v in sorted(got.items()) if v.startswith("err:")]
+    return (not errs), "; ".join(errs)
+
+
 def allreduce_sums(sums: np.ndarray, group=None) -> np.ndarray:
     """Sum the partial-sum buffers of all ranks (no-op without an initialised process group)."""
     import torch

@@ -128,14 +128,21 @@ class Engine:
         _lib.check(self.lib.mmhn_cohort_sums_end(self.h, sums.ctypes.data_as(f64p)))
         return sums
 
-    def cohort_wsums_begin(self, log_theta, log_d_p, log_d_m, w, with_grad=True):
-        """Like cohort_sums_begin with the EM / NM weighting applied on the device (mmhn_cohort_wsums_begin)."""
+    def cohort_wsums_begin(self, log_theta, log_d_p, log_d_m, w, with_grad=True, flag=None):
+        """Like cohort_sums_begin with the EM / NM weighting applied on the device (mmhn_cohort_wsums_begin).
+        flag (optional): one more double that rides in the same all-reduce (mmhn_set_reduce_flag); its sum over the ranks is
+        `reduce_flag` after cohort_wsums_end."""
         keep, (a, b, c) = self._params(log_theta, log_d_p, log_d_m)
+        if flag is not None:
+            _lib.check(self.lib.mmhn_set_reduce_flag(self.h, float(flag)))
         _lib.check(self.lib.mmhn_cohort_wsums_begin(self.h, a, b, c, int(bool(with_grad)), float(w)))
 
     def cohort_wsums_end(self):
         ws = np.zeros(1 + self.N * self.N + 2 * self.N)
         _lib.check(self.lib.mmhn_cohort_wsums_end(self.h, ws.ctypes.data_as(f64p)))
+        out = C.c_double()
+        _lib.check(self.lib.mmhn_get_reduce_flag(self.h, C.byref(out)))
+        self.reduce_flag = out.value
         return ws
 
     def patient_grads(self, log_theta, log_d_p, log_d_m, with_grad=True):

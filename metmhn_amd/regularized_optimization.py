@@ -62,8 +62,6 @@ def _join_comm(eng: Engine, rank: int, world: int) -> bool:
     every rank destroys its half and all of them use torch's collective (no rank is ever left alone in one of the two).
     MMHN_COMM_TIMEOUT (seconds, default 180): a rank whose ncclCommInitRank does not return fails instead of hanging."""
     import os
-    import threading
-    import torch
     import torch.distributed as dist
     from .engine import unique_id
     if world > 1 and dist.get_backend() != "nccl":
@@ -78,38 +76,28 @@ def _join_comm(eng: Engine, rank: int, world: int) -> bool:
             err = exc
     if world > 1:
         dist.broadcast_object_list(box, src=0)                # always entered by every rank
-    ok = box[0] is not None
-    if ok:
-        res = {}
-
-        def _init():
-            try:
-                eng.comm_init(box[0], rank, world)
-                res["ok"] = True
-            except Exception as exc:                          # noqa: BLE001
-                res["err"] = exc
-
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(float(os.environ.get("MMHN_COMM_TIMEOUT", "180")))
-        if th.is_alive():
-            raise TimeoutError("metmhn_amd: ncclCommInitRank did not return within MMHN_COMM_TIMEOUT - a rank is missing")
-        ok = bool(res.get("ok"))
-        err = res.get("err", err)
-    if world > 1:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        all_ok = bool(int(flag.item()))
+    if box[0] is None:
+        all_ok, msg = False, f"rank 0 could not create an RCCL id ({err})"
     else:
-        all_ok = ok
+        store = None
+        if world > 1:
+            from torch.distributed.distributed_c10d import _get_default_store
+            store = _get_default_store()
+        # (no collective in here: a rank that fails before ncclCommInitRank tells the others through the store, and a rank
+        # still blocked in it gives up within a fraction of a second instead of after MMHN_COMM_TIMEOUT - distributed.py)
+        all_ok, msg = _dist.collective_init(lambda: eng.comm_init(box[0], rank, world), rank, world, store,
+                                            timeout=float(os.environ.get("MMHN_COMM_TIMEOUT", "180")))
     if all_ok:
         return True
-    if ok:
-        eng.comm_destroy()                                    # some other rank failed: nobody uses the device communicator
+    if getattr(eng, "comm_size", 1) > 1 or box[0] is not None:
+        try:
+            eng.comm_destroy()                                # some other rank failed: nobody uses the device communicator
+        except Exception:                                     # noqa: BLE001
+            pass
     if strict:
-        raise RuntimeError(f"metmhn_amd: in-library RCCL communicator unavailable on some rank ({err})")
+        raise RuntimeError(f"metmhn_amd: in-library RCCL communicator unavailable on some rank ({msg})")
     import warnings
-    warnings.warn(f"metmhn_amd: in-library RCCL communicator unavailable ({err}); using torch.distributed")
+    warnings.warn(f"metmhn_amd: in-library RCCL communicator unavailable ({msg}); using torch.distributed")
     return False
 
 
@@ -127,11 +115,14 @@ _CRC_ROWS = {}
 def _digest(arr: np.ndarray) -> int:
     """64-bit digest of a contiguous array: xxh3 where the package is there (13 us for the 208 KB of the LUAD-reduced
     cohort - zlib's CRC takes 240 us, longer than a score-only evaluation of that cohort), else zlib.crc32."""
+    if arr.size == 0:
+        return 0
+    flat = arr.reshape(-1).view(np.uint8)                     # (memoryview.cast refuses shapes with a zero in them)
     try:
-        import xxhash
-        return xxhash.xxh3_64_intdigest(memoryview(arr).cast("B"))
+        import xxhash                                         # optional: `pip install metmhn_amd[fast]`
     except ImportError:
-        return zlib.crc32(arr.tobytes())
+        return zlib.crc32(flat)
+    return xxhash.xxh3_64_intdigest(flat)
 
 
 def _sample_crc(dat: np.ndarray) -> int:
@@ -202,7 +193,8 @@ def _load_rows(eng: Engine, dat, rank: int, world: int, arr=None):
 
 def _stale_anywhere(eng: Engine, dat, world: int) -> bool:
     """Has `dat` been edited in place since `eng` laid it out - on ANY rank (the ranks must decide together: a rebuild
-    and the repeated evaluation are collective)?"""
+    and the repeated evaluation are collective)?  Used where an engine is fetched outside an evaluation; inside one the bit
+    rides in the evaluation's own all-reduce (_result)."""
     stale = isinstance(dat, np.ndarray) and eng._sample_crc != _sample_crc(dat)
     if world > 1:
         import torch
@@ -211,14 +203,6 @@ def _stale_anywhere(eng: Engine, dat, world: int) -> bool:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         stale = bool(int(flag.item()))
     return stale
-
-
-def _stale_anywhere_flag(stale: bool) -> bool:
-    import torch
-    import torch.distributed as dist
-    flag = torch.tensor([1 if stale else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    return bool(int(flag.item()))
 
 
 def _reduce_mode():
@@ -236,21 +220,34 @@ def _result(eng: Engine, log_theta, log_d_p, log_d_m, perc_met: float, with_grad
     does the cache guard of `guard` (the caller's `dat`, engine from _engine_for(dat, check=False)): if the array was
     edited in place since its layout was built, the result is dropped and the evaluation repeated on a fresh layout."""
     w, n_full = _dist.em_weight(*eng._global_counts, perc_met)
-    eng.cohort_wsums_begin(log_theta, log_d_p, log_d_m, w, with_grad=with_grad)
+    guarded = isinstance(guard, np.ndarray)                   # (anything else was keyed by content: cannot be stale)
+    many = eng._sharded and eng.world_size_hint > 1
     stale = False
+    if many and guarded:
+        # several ranks must decide TOGETHER whether to rebuild: the bit rides in the evaluation's own all-reduce (one
+        # collective per evaluation, SURVEY 8e), so the guard runs before the launch here (13 us on a LUAD-sized array)
+        stale = eng._sample_crc != _sample_crc(guard)
+    eng.cohort_wsums_begin(log_theta, log_d_p, log_d_m, w, with_grad=with_grad, flag=(1.0 if stale else 0.0) if many and guarded else None)
     try:
-        stale = isinstance(guard, np.ndarray) and eng._sample_crc != _sample_crc(guard)
+        if not many:
+            stale = guarded and eng._sample_crc != _sample_crc(guard)          # one rank: next to the GPU
         aside = meanwhile() if meanwhile is not None and not stale else None
     finally:
         ws = eng.cohort_wsums_end()
-    if guard is not None and eng._sharded and eng.world_size_hint > 1:
-        stale = _stale_anywhere_flag(stale)
+    if eng._sharded and not eng._device_comm:
+        ext = np.append(ws, 1.0 if (stale and many and guarded) else 0.0)       # (the same bit through torch's collective)
+        ext = _dist.allreduce_sums_fixed_order(ext) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(ext)
+        ws, stale_any = ext[:-1], ext[-1] > 0
+    else:
+        stale_any = eng.reduce_flag > 0
+    if many and guarded:
+        stale = bool(stale_any)
     if stale:
         rank, world = _rank_world() if _OPTIONS["shard"] else (0, 1)
         _load_rows(eng, guard, rank, world)                   # the same engine (and communicator), the new rows
         return _result(eng, log_theta, log_d_p, log_d_m, perc_met, with_grad, meanwhile)
-    if eng._sharded and not eng._device_comm:
-        ws = _dist.allreduce_sums_fixed_order(ws) if _reduce_mode() == "host_fixed_order" else _dist.allreduce_sums(ws)
+    if aside is None and meanwhile is not None:
+        aside = meanwhile()
     return _dist.split_wsums(ws, eng.N, n_full), aside
 
 

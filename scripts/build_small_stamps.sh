@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 rm -rf build_ab/ssrc && mkdir -p build_ab/ssrc && cp metmhn_amd/csrc/* build_ab/ssrc/
-sed -i 's/STAMP_FLUSH(TR ? 8 : 0);//' build_ab/ssrc/kernels.h build_ab/ssrc/msolve.h
+sed -i 's/STAMP_FLUSH(TR ? 8 : 0);//' build_ab/ssrc/kernels.h build_ab/ssrc/wsolve.h build_ab/ssrc/tsolve.h
 python3 - <<'PY'
 p = 'build_ab/ssrc/small.h'
 s = open(p).read()

@@ -193,6 +193,61 @@ def test_two_rank_precombined_payload_fixed_order(golden):
     np.testing.assert_allclose(res[3], g["c1_d_dm"], rtol=1e-10, atol=1e-13)
 
 
+def _worker_comm_setup(rank, world, port, q, case):
+    """collective_init over the store of a 2-rank gloo job (the RCCL set-up itself is stood in for by `init_fn`)."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.distributed.distributed_c10d import _get_default_store
+    from metmhn_amd import distributed as D
+
+    def init_fn():
+        if case == "one_fails_early" and rank == 0:
+            raise RuntimeError("cannot load RCCL")            # fails BEFORE entering the collective set-up
+        if case == "one_fails_early":
+            time.sleep(120)                                   # ... while its peer sits in ncclCommInitRank
+        if case == "all_fail":
+            raise RuntimeError(f"no device on rank {rank}")
+
+    t0 = time.monotonic()
+    try:
+        out = D.collective_init(init_fn, rank, world, _get_default_store(), timeout=60.0)
+        q.put((rank, "returned", out, time.monotonic() - t0))
+    except D.CommAbandoned as exc:
+        q.put((rank, "abandoned", str(exc), time.monotonic() - t0))
+    dist.barrier() if case != "one_fails_early" else None     # (the abandoned job is expected to end; no collective after it)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["all_ok", "all_fail", "one_fails_early"])
+def test_communicator_setup_is_decided_through_the_store(case):
+    """a rank that fails before ncclCommInitRank must not leave its peers in it for MMHN_COMM_TIMEOUT.
+    The set-up is decided through the torch.distributed store (metmhn_amd/distributed.py: collective_init): all ok -> True on
+    every rank; every rank failing quickly -> (False, messages) on every rank (they fall back together); one rank failing
+    early while the other is still blocked -> BOTH give up within seconds (CommAbandoned), not after the 60 s timeout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_comm_setup, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    if case == "all_ok":
+        assert all(r[1] == "returned" and r[2] == (True, "") for r in res), res
+    elif case == "all_fail":
+        assert all(r[1] == "returned" and r[2][0] is False and "no device on rank 0" in r[2][1] and "rank 1" in r[2][1] for r in res), res
+    else:
+        assert all(r[1] == "abandoned" for r in res), res
+        assert "cannot load RCCL" in res[1][2]                # the blocked rank names the failure it saw
+        assert max(r[3] for r in res) < 15.0, res             # seconds, not the timeout
+
+
 def test_cohort_cache_guard_notices_in_place_edits():
     from metmhn_amd import regularized_optimization as ro, synthetic
     dat = synthetic.mixed_cohort(5, 300, seed=3)

@@ -1222,6 +1222,8 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
         _row(n, range(5), range(5, 15), 0),                     # kM = 10 rows, no pair, k = 16: no external bits
         _row(n, range(10), range(10, 15), 1),                   # k = 16, kP = 10 rows
         _row(n, range(12), [12, 13], 0),                        # k = 15: too few column bits for the window path
+        _row(n, range(2, 15), range(12, 18), 0),                # kP = 13, kM = 6 again (three pairs) ...
+        _row(n, range(1, 14), [0, 3, 14, 15, 16, 19], 1),       # ... and a third one: a same-shape chain of three
     ]
     # (a) mixed shapes: the single-tumour spaces of the large rows exceed a tile -> staged marginal kernels (k_gather_marg);
     # (b) rows whose marginal spaces fit a tile -> the small-space kernels read the window layout (small.h);
@@ -1245,6 +1247,20 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
             for x, y in zip(r1, res[2]):
                 assert np.isfinite(x).all()
                 np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11)
+        #  the same cohorts with ONE and TWO workgroups: every same-shape run becomes one chain (patients at chain
+        # position > 0: both table buffers re-used, patients entering / leaving the pipeline mid-stream, pinfo of the second
+        # buffer), and there are more chains than workgroups (the longest-first deal with filler entries)
+        monkeypatch.setenv("MMHN_WSOLVE", "1")
+        for wgs in ("1", "2"):
+            monkeypatch.setenv("MMHN_WSOLVE_WGS", wgs)
+            e = Engine(n)
+            e.set_cohort(dat)
+            r1 = e.patient_grads(lt, dp, dm)
+            e.close()
+            for x, y in zip(r1, res[2]):
+                assert np.isfinite(x).all()
+                np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-11, err_msg=f"MMHN_WSOLVE_WGS={wgs}")
+        monkeypatch.delenv("MMHN_WSOLVE_WGS")
 
 
 
@@ -1281,8 +1297,14 @@ def test_window_path_fp32_k25_shapes(monkeypatch):
     for tag, cohort in (("k25", k25), ("mixed", mixed)):
         dat = np.array(cohort, dtype=np.int8)
         lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
-        for ms in ("1", "0"):
+        # (ms, workgroups): "1" with ONE / TWO workgroups chains every same-shape run - the three (12, 12) rows become one
+        # chain of three, the extreme shapes run at chain positions > 0 of a workgroup that changes shape
+        for ms, wgs in (("1", None), ("0", None), ("1", "1"), ("1", "2")):
             monkeypatch.setenv("MMHN_WSOLVE", ms)
+            if wgs is None:
+                monkeypatch.delenv("MMHN_WSOLVE_WGS", raising=False)
+            else:
+                monkeypatch.setenv("MMHN_WSOLVE_WGS", wgs)
             e = Engine(n, dtype="f32")
             e.set_cohort(dat)
             res = e.patient_grads(lt, dp, dm)
@@ -1290,8 +1312,9 @@ def test_window_path_fp32_k25_shapes(monkeypatch):
             assert all(np.isfinite(x).all() for x in res)
             np.testing.assert_allclose(res[0], lp, rtol=1e-4)
             for x32, x64, nm in ((res[1], g, "d_theta"), (res[2], a, "d_dp"), (res[3], b, "d_dm")):
-                err, tol = _fp32_report(f"{tag} WSOLVE={ms} {nm}", x32, x64)
-                assert (err <= tol).all(), (tag, ms, nm)
+                err, tol = _fp32_report(f"{tag} WSOLVE={ms} WGS={wgs} {nm}", x32, x64)
+                assert (err <= tol).all(), (tag, ms, wgs, nm)
+        monkeypatch.delenv("MMHN_WSOLVE_WGS", raising=False)
 
 
 def _rccl_worker(rank, world, port, q):
