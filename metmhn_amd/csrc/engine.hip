@@ -507,7 +507,8 @@ struct Engine : EngineBase {
   bool force_timing = false;    // MMHN_TIME_KERNELS=1: HIP events around the solve / class-marginal launches of every batch (bench
                                 // breakdowns of small cohorts; an event pair costs the host ~10 us)
   int pcl_per = 16;             // MMHN_PCL_PER: tiles of a class pass per work item of k_pclass
-  int coop_wgs = 0;             // MMHN_COOP_WGS: workgroups of a cooperative launch (default: two per CU)
+  int coop_wgs = 0;             // MMHN_COOP_WGS: workgroups of a cooperative launch (default: one per CU - with two the launch holds every
+                                // wave slot of the chip and the side streams' kernels wait for its end: 1.65 against 1.47 ms on the 28-event LUAD cohort)
   bool coop = true;             // MMHN_COOP=0: tile solves as one launch per level (k_tsolve) instead of one cooperative launch
   // cooperative launches (tsolve.h): queue heads + abort word, the flags of the tiles (value = epoch of the launch that
   // finished the tile), the pinned host copy of the abort word
@@ -921,7 +922,7 @@ struct Engine : EngineBase {
       const int slot = cur_lane * 4 + coop_slot;
       coop_used = true;
       timed(L.kslot, per_tile * nitems, [&]() {
-        const dim3 g((unsigned)std::min(nitems, coop_wgs > 0 ? coop_wgs : CS_WG_PER_CU * n_cu)), bk(TSB);
+        const dim3 g((unsigned)std::min(nitems, coop_wgs > 0 ? coop_wgs : n_cu)), bk(TSB);
 #define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, flags.p, coop_epoch, coop_ctl.p, slot, h_abort_dev, \
                 y, lidg, rhs, rhs_mode, scal, d_perm.p, mk, L.tab, links.p, qS.p
         if (lidg) {

@@ -212,6 +212,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   auto deskew = [&]() { for (int s = lam; s < WWB; ++s) lds_barrier(); };
   auto reskew = [&]() { for (int s = 0; s < lam; ++s) lds_barrier(); };
 
+  // (formed once: inside the chain loop the addresses of wrho's tables were kept over the step loop and spilled)
+  const uint32_t voff = wrho((uint32_t)tid >> 6, (uint32_t)tid & 63u) * (uint32_t)sizeof(VecT);
   STAMP_DECL;
   for (int ci = blockIdx.x; ci < nchains; ci += gridDim.x) {
     STAMP_START;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     // ---- a patient enters: its tables (buffer j & 1), forward: its seed = 0 lattice (only PT == MT states carry values).
     // Every wave is at the same point here (deskew); the ring is dead.
     auto solve_eq = [&](const WDesc& wd, const Desc& d, T* se) {
+      const int tid = (int)opaque_tid();                       // (per-thread addresses formed here, not hoisted over the step loop and spilled)
       const long long base = d.off;
       const T* dP = tab + d.toff + rate_table_size(k);
       const T* dE = dP + (1ll << __popc(d.maskP)) + (1ll << __popc(d.maskM));
@@ -283,10 +286,12 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       }
     };
     auto load_thc = [&](const Desc& d) {
+      const int tid = (int)opaque_tid();
       const T* src = tab + d.toff;
       for (int e = tid; e < k * k; e += WROWS) thc[e] = src[e];
     };
     auto enter = [&](int j) {
+      const int tid = (int)opaque_tid();
       const WDesc& wd = wds[first + j];
       const Desc& d = descs[wd.prob];
       T* const tb = lds + L::tab0 + (j & 1) * L::TABSZ;
@@ -386,6 +391,10 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       r.q[1] = *reinterpret_cast<const u32x4*>(p + QE);
       return __builtin_bit_cast(VecT, r);
     };
+    // the first patient enters (before the per-lane state of the passes exists: it would be kept in registers over the
+    // set-up and spilled)
+    enter(0);
+    reskew();
     VecT Wd[H];                                                // the window
 #pragma unroll
     for (int b = 0; b < H; ++b)
@@ -398,7 +407,6 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     T cL[WLB], dRv = T(1);
     uint32_t hitT = 0xffffffffu, hitE = 0;
     uint32_t rowkey = 0xffffffffu;                             // (patient, external row setting) the row constants were formed for
-    const uint32_t voff = wrho((uint32_t)tid >> 6, (uint32_t)tid & 63u) * (uint32_t)sizeof(VecT);
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
       const int V = sig - (TR ? WLB - __popc(ln) : __popc(ln));
@@ -679,8 +687,6 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     // ---- the pipeline: wave-level lam delays the wave by lam steps, lane-level m delays a lane by m window passes;
     // a patient enters every 2^nX passes (the waves meet for its tables: four steps of slack) and, transposed, is
     // completed by its seed = 0 lattice six passes after the next one entered
-    enter(0);
-    reskew();
     for (int sig = 0; sig < NPASS; ++sig) {
       const uint32_t ph = (uint32_t)sig & (NXS - 1u);
       const int jj = sig >> nX;
