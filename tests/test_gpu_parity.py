@@ -831,28 +831,41 @@ def test_luad28_real_workload(monkeypatch, golden):
 
 
 def test_luad_fit_reaches_published_objective(golden):
-    """learn_mhn from indep(dat) with the reference's own LUAD settings (perc_met 0.2, lambda 1e-3,
-    ftol 1e-5; examples/data_analysis.ipynb cell 14).  The engine's objective equals the reference's at the published
-    parameters (results/luad/luad_g14_20muts.csv, evaluated by the reference in luad_fit.npz).  Those parameters are
-    NOT the optimum of that objective: SciPy's L-BFGS-B on the CPU oracle (oracle/metmhn_ref.c) goes from the same
-    start to 5.47856 in 48 iterations against 5.94956 at the published point - so the engine's fit must do at least
-    as well as the published point and land where the CPU optimiser lands."""
+    """SURVEY 8f-1: learn_mhn from indep(dat) with the reference's own LUAD settings (perc_met 0.2, lambda 1e-3;
+    examples/data_analysis.ipynb cell 14).  (a) The engine's objective equals the reference's at the published parameters
+    (results/luad/luad_g14_20muts.csv, evaluated by the reference in luad_fit.npz).  Those parameters are NOT the optimum of
+    that objective (5.94956 there), so the fit is compared with what the SAME optimiser reaches on the CPU oracle: (b)
+    tests/golden/luad_cpu_fit.npz holds SciPy's L-BFGS-B on oracle/metmhn_ref.c from the same start with ftol 1e-10
+    (tests/tools/make_golden_luad_cpu_fit.py: 151 iterations, objective 5.4774638); the engine's fit with the same stopping rule
+    must reach that objective to 1e-7 relative and those parameters to 1e-3."""
     import os
-    if not (os.path.exists(os.path.join(GOLDEN, "luad_indep.npz")) and os.path.exists(os.path.join(GOLDEN, "luad_fit.npz"))):
-        pytest.skip("LUAD fixtures not generated")
+    for f in ("luad_indep.npz", "luad_fit.npz", "luad_cpu_fit.npz"):
+        if not os.path.exists(os.path.join(GOLDEN, f)):
+            pytest.skip("LUAD fixtures not generated")
     import metmhn_amd.regularized_optimization as ro
-    gi, gf = golden("luad_indep"), golden("luad_fit")
+    gi, gf, gc = golden("luad_indep"), golden("luad_fit"), golden("luad_cpu_fit")
     dat = gi["dat"]
     pf = np.concatenate((gf["fit_theta"].flatten(), gf["fit_dp"], gf["fit_dm"]))
     v_pub, g_pub = ro.score_and_grad_reg(pf, dat, 0.2, ro.symmetric_penal, 1e-3)
     np.testing.assert_allclose(v_pub, gf["fit_reg_value"], rtol=1e-9)
     np.testing.assert_allclose(g_pub, gf["fit_reg_grad"], rtol=1e-6, atol=1e-9)
+    # the engine at the CPU optimiser's end point: same objective, and a gradient as small as the CPU's
+    pc = np.concatenate((gc["theta"].flatten(), gc["dp"], gc["dm"]))
+    v_c, g_c = ro.score_and_grad_reg(pc, dat, 0.2, ro.symmetric_penal, 1e-3)
+    np.testing.assert_allclose(v_c, float(gc["objective"]), rtol=1e-10)
+    assert np.linalg.norm(g_c) <= 2.0 * float(gc["grad_norm"]) + 1e-9
     th, dp, dm = ro.learn_mhn(gi["indep_theta"], gi["indep_dp"], gi["indep_dm"], dat, 0.2, ro.symmetric_penal, 1e-3,
-                              opt_ftol=1e-5, opt_v=False)
+                              opt_ftol=float(gc["ftol"]), opt_v=False)
     v_fit = float(ro.score_reg(np.concatenate((th.flatten(), dp, dm)), dat, 0.2, ro.symmetric_penal, 1e-3))
     assert v_fit < float(gf["fit_reg_value"])
-    CPU_OPTIMUM = 5.47856203029577          # same optimiser, start and settings on the CPU oracle (48 iterations)
-    assert abs(v_fit - CPU_OPTIMUM) <= 2e-3 * CPU_OPTIMUM
+    assert abs(v_fit - float(gc["objective"])) <= 1e-7 * float(gc["objective"]), (v_fit, float(gc["objective"]))
+    # parameters: events the cohort never shows sit at indep()'s -1e10-like floor on both sides; compare through exp
+    # for the diagonal (base rates) and directly elsewhere
+    np.testing.assert_allclose(np.exp(np.diag(th)), np.exp(np.diag(gc["theta"])), rtol=1e-3, atol=1e-6)
+    off = ~np.eye(th.shape[0], dtype=bool)
+    np.testing.assert_allclose(th[off], gc["theta"][off], atol=1e-3)
+    np.testing.assert_allclose(dp, gc["dp"], atol=1e-3)
+    np.testing.assert_allclose(dm, gc["dm"], atol=1e-3)
 
 
 def test_staged_and_fused_small_paths_agree(monkeypatch, golden):
