@@ -34,8 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r4_traffic.json")
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r4_counters.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_traffic.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r5_counters.json")
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector: half of the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md
 
 
@@ -373,7 +373,7 @@ def main():
         tsrc = traffic.get("source", {})
         if tsrc.get("csrc_sha16") != csrc_sha16():      # PMC passes of another tree: not quoted
             traffic = {}
-        traffic_source = (f"recorded offline: profiles/r4_traffic.json (git {tsrc.get('git_head', '?')}, csrc {tsrc.get('csrc_sha16', '?')}; "
+        traffic_source = (f"recorded offline: profiles/r5_traffic.json (git {tsrc.get('git_head', '?')}, csrc {tsrc.get('csrc_sha16', '?')}; "
                           "rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes over this same command; "
                           "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)")
         traffic_ok = a.workload == "full-k" and n == 20 and a.dtype == "f64" and a.patients == 5000 and bool(traffic)
@@ -413,7 +413,7 @@ def main():
                 o["frac_of_measured_copy"] = ach / stream["copy_GBps"]
             # what bounds the kernel besides HBM (solves only): useful fp64 FMAs of the substitution = one per existing move
             # of every seeded state + one for the diagonal = 2^K (K / 2 + 1) per patient (K = k - 1 index bits of the seeded
-            # half), against the fp64 vector peak; instruction counters from a separate PMC pass (profiles/r4_counters.json)
+            # half), against the fp64 vector peak; instruction counters from a separate PMC pass (profiles/r5_counters.json)
             if name in ("psolve_fwd", "psolve_adj") and a.workload == "full-k":
                 K = n - 1
                 fmas = per_launch / esz * (K / 2.0 + 1.0)          # (states written by the launch) x (K / 2 + 1)
@@ -429,7 +429,7 @@ def main():
                     o["wave_insts_per_64_states"] = sum(ck.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
                                                                                  "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")) / states64
                     o["waves_per_simd"] = ck.get("waves_per_simd")
-                    o["counters_source"] = f"recorded offline: profiles/r4_counters.json (git {counters['source'].get('git_head', '?')}), rocprofv3 --pmc SQ_INSTS_*"
+                    o["counters_source"] = f"recorded offline: profiles/r5_counters.json (git {counters['source'].get('git_head', '?')}), rocprofv3 --pmc SQ_INSTS_*"
             return o
 
         T = "double" if a.dtype == "f64" else "float"
@@ -440,7 +440,7 @@ def main():
                       "solution written once: the seeded half, 2^(k-1) x sizeof(dtype) per patient")
         rf_adj = kern("psolve_adj", f"{ksolve}<{T},true> (adjoint substitution solve)", "solution written once")
         rf_marg = kern("pclass", f"{'k_wclass' if wsolve else 'k_pclass'}<{T}> (class marginals of pi (x) q)", "pi and q_J read once (seeded halves)")
-        rf_other = kern("other_solve", "k_tsolve / k_sweep (level-by-level solves of the marginal single-tumour problems)",
+        rf_other = kern("other_solve", "k_csolve / k_tsolve (tile solves of the single-tumour problems of more than a tile: one cooperative launch each)",
                         "per tile: solution written once (+ dense rhs / lidg vector reads)")
         # the patient shards: rows and LPT cost (2^k (k + 1), distributed.patient_cost) per rank
         from metmhn_amd import distributed as D
@@ -465,7 +465,8 @@ def main():
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
                        "rccl_ranks": cnt.get("comm_ranks", 0), "rccl_rank": cnt.get("comm_rank", -1), "shards": shard,
-                       "solver": os.environ.get("MMHN_SOLVER", "substitution (k_wsolve: window layout, chains of patients; k_tsolve for the marginals)"),
+                       "solver": os.environ.get("MMHN_SOLVER", "substitution, per-problem dispatch (k_wsolve: window layout, chains of patients; k_psolve2: one workgroup "
+                                                               "per patient; k_csolve: all remaining tiles in one cooperative launch)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},
             # dominant kernel of the timed step
             "roofline": dominant,

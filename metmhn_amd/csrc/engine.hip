@@ -496,7 +496,6 @@ struct Engine : EngineBase {
   bool poison = false;          // MMHN_POISON=1: NaN-fill the solution buffers of per-patient batches before each evaluation
   hipStream_t side[3] = {};               // side streams: [0], [1] of the small-space path, [2] of the staged own-problem patients
   hipEvent_t ev_fork[3] = {}, ev_join[3] = {};
-  int kv_version = 2;           // MMHN_KV=1: the round-1 kronvec kernel (k_sweep) also for plain products on multi-tile spaces
   bool small_path = true;       // MMHN_SMALL=0: keep the staged kernels for single-tumour spaces that fit one tile
   int prep_split_max = 2048;    // MMHN_PREP_SPLIT: problems up to which k_prep / k_pclass run a workgroup per table / class pass
   bool pair_small = true;       // MMHN_PAIR_SMALL=0: the two marginal problems of a paired row one after the other
@@ -506,6 +505,7 @@ struct Engine : EngineBase {
                                 // follows MMHN_PSOLVE_MIN when only that one is set)
   bool force_timing = false;    // MMHN_TIME_KERNELS=1: HIP events around the solve / class-marginal launches of every batch (bench
                                 // breakdowns of small cohorts; an event pair costs the host ~10 us)
+  bool coop_fault = false;      // MMHN_COOP_FAULT=1 (tests): the first tile of every cooperative launch never raises its flag
   int pcl_per = 16;             // MMHN_PCL_PER: tiles of a class pass per work item of k_pclass
   int coop_wgs = 0;             // MMHN_COOP_WGS: workgroups of a cooperative launch (default: one per CU - with two the launch holds every
                                 // wave slot of the chip and the side streams' kernels wait for its end: 1.65 against 1.47 ms on the 28-event LUAD cohort)
@@ -570,12 +570,12 @@ struct Engine : EngineBase {
       if (const char* pm = std::getenv("MMHN_TIME_KERNELS")) force_timing = std::atoi(pm) != 0;
       if (const char* pm = std::getenv("MMHN_COOP_WGS")) coop_wgs = std::atoi(pm);
       if (const char* pm = std::getenv("MMHN_PCL_PER")) pcl_per = std::max(1, std::atoi(pm));
+      if (const char* pm = std::getenv("MMHN_COOP_FAULT")) coop_fault = std::atoi(pm) != 0;
       if (const char* po = std::getenv("MMHN_POISON")) poison = std::atoi(po) != 0;
       if (const char* sp = std::getenv("MMHN_SMALL")) small_path = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PAIR_SMALL")) pair_small = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_ZEROCOPY")) zero_copy = std::atoi(sp) != 0;
       if (const char* sp = std::getenv("MMHN_PREP_SPLIT")) prep_split_max = std::atoi(sp);
-      if (const char* kvv = std::getenv("MMHN_KV")) kv_version = std::atoi(kvv);
       if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE_CHAIN")) wsolve_chain = std::atoi(ms);
@@ -923,7 +923,7 @@ struct Engine : EngineBase {
       coop_used = true;
       timed(L.kslot, per_tile * nitems, [&]() {
         const dim3 g((unsigned)std::min(nitems, coop_wgs > 0 ? coop_wgs : n_cu)), bk(TSB);
-#define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, flags.p, coop_epoch, coop_ctl.p, slot, h_abort_dev, \
+#define CS_ARGS g, bk, lds, stream, L.d, cl.d_items.p, cl.d_deps.p, nitems, flags.p, coop_epoch, coop_ctl.p, slot, h_abort_dev, coop_fault ? 1 : 0, \
                 y, lidg, rhs, rhs_mode, scal, d_perm.p, mk, L.tab, links.p, qS.p
         if (lidg) {
           if (tr) hipLaunchKernelGGL((k_csolve<T, true, true>), CS_ARGS);
@@ -1776,7 +1776,7 @@ struct Engine : EngineBase {
     const size_t V = (size_t)1 << d.k;
     up(m.a, p, V);
     m.b.alloc(V);
-    if (d.k > TB && kv_version == 2) {
+    if (d.k > TB) {
       std::vector<int2> live;
       for (int tl = 0; tl < m.ntiles; ++tl) if (!dead_tile(m.d, (uint32_t)tl)) live.push_back(make_int2(0, tl));
       DevArr<int2> dlive;
@@ -1844,7 +1844,7 @@ struct Engine : EngineBase {
     HIPCHECK(hipMemcpyAsync(kb.map.p, mp.data(), mp.size() * sizeof(int2), hipMemcpyHostToDevice, stream));
     kb.tab.alloc((size_t)std::max<long long>(table_size(d0), 1));
     prep(kb.dd.p, 1, kb.tab.p);                    // one table: every vector lives in the same space
-    kb.use_kv = d0.k > TB && kv_version == 2;
+    kb.use_kv = d0.k > TB;
     if (kb.use_kv) {
       kb.hxl.alloc(lv.size() * (size_t)d0.k);
       hipLaunchKernelGGL((k_hx<T>), dim3((unsigned)kb.nlive), dim3(64), 0, stream, kb.dd.p, kb.live.p, kb.tab.p, kb.hxl.p, d0.k);
@@ -2037,8 +2037,7 @@ struct Engine : EngineBase {
     }
     // the timed launch is exactly the one mmhn_kronvec_batched issues (plain product), or the fused Jacobi step
     auto run = [&]() {
-      if (jacobi && kv_version != 2) launch_sweep(tr, kb.dd.p, kb.map.p, kb.ntiles, d0.k, a.p, b.p, c.p, r.p, 0, nullptr, 0, kb.tab.p);
-      else if (jacobi) kv_launch(kb, tr, a.p, b.p, c.p, r.p);
+      if (jacobi) kv_launch(kb, tr, a.p, b.p, c.p, r.p);
       else kv_launch(kb, tr, a.p, b.p);
     };
     run(); run();

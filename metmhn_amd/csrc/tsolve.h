@@ -43,9 +43,16 @@ struct CoopCtl {
   unsigned abort;    // != 0: a spin timed out
   unsigned pad[7];
 };
-#ifndef MMHN_CS_WPE
-#define MMHN_CS_WPE TSB_WPE      // waves per SIMD k_csolve's register budget is sized for (8: two workgroups per CU, 4: one)
+#ifndef MMHN_TS_WPE
+#define MMHN_TS_WPE TSB_WPE      // waves per SIMD the tile solvers' register budget is sized for (8: two workgroups per CU, 4: one)
 #endif
+#ifndef MMHN_CS_WPE
+#define MMHN_CS_WPE MMHN_TS_WPE
+#endif
+#ifndef MMHN_TS_TRIP
+#define MMHN_TS_TRIP 3           // in-tile moves of a state whose LDS loads are issued together (step B)
+#endif
+constexpr int TS_WPE = MMHN_TS_WPE;
 constexpr int CS_WPE = MMHN_CS_WPE;
 constexpr int CS_WG_PER_CU = CS_WPE * 256 / TSB;
 #ifndef MMHN_CS_SLEEP
@@ -247,17 +254,18 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
       T z = yt[xl];
       uint32_t todo = TR ? (~xl & tmask) : xl;
       if (fast) {
-        while (todo) {                         // three bits per trip: their 9 LDS loads are issued together
-          T r[3];
+        while (todo) {                         // MMHN_TS_TRIP bits per trip: their LDS loads are issued together
+          T r[MMHN_TS_TRIP];
 #pragma unroll
-          for (int u = 0; u < 3; ++u) {
+          for (int u = 0; u < MMHN_TS_TRIP; ++u) {
             const bool on = todo != 0;
             const int b = on ? __ffs(todo) - 1 : 0;
             todo &= todo - 1;                  // 0 stays 0
             const T v = Ltab[b * 64 + lo] * Utab[b * 64 + ro] * yt[xl ^ (1u << b)];
             r[u] = on ? v : T(0);
           }
-          z += r[0] + r[1] + r[2];
+#pragma unroll
+          for (int u = 0; u < MMHN_TS_TRIP; ++u) z += r[u];
         }
       } else {
         const uint32_t x = xhi | xl;
@@ -299,7 +307,7 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
 
 // one launch per level of tile-index popcount (host: Engine::solve)
 template <typename T, bool TR, bool LIDGV>
-__global__ __launch_bounds__(TSB, TSB_WPE) void k_tsolve(const Desc* __restrict__ descs,
+__global__ __launch_bounds__(TSB, TS_WPE) void k_tsolve(const Desc* __restrict__ descs,
                                                 const int2* __restrict__ lmap,
                                                 const Params<T>* __restrict__ par, T* y,
                                                 const T* __restrict__ lidg,
@@ -320,12 +328,12 @@ __global__ __launch_bounds__(TSB, TSB_WPE) void k_tsolve(const Desc* __restrict_
 // ------------------------------------------------------------------------------------
 // k_csolve: every tile of every problem of a list in ONE launch (see the head of this file).
 //   items / deps: the work list of this direction;  flags[i] == epoch: item i of this launch is stored and visible;
-//   ctl->head[slot]: queue head;  h_abort: the pinned host copy of ctl->abort.
+//   ctl->head[slot]: queue head;  h_abort: the pinned host copy of ctl->abort;  fault: test hook (see the publish step).
 // ------------------------------------------------------------------------------------
 template <typename T, bool TR, bool LIDGV>
 __global__ __launch_bounds__(TSB, CS_WPE) void k_csolve(const Desc* __restrict__ descs,
                                                 const CItem* __restrict__ items, const int* __restrict__ deps, int nitems,
-                                                unsigned* flags, unsigned epoch, CoopCtl* ctl, int slot, unsigned* h_abort,
+                                                unsigned* flags, unsigned epoch, CoopCtl* ctl, int slot, unsigned* h_abort, int fault,
                                                 T* y, const T* __restrict__ lidg,
                                                 const T* __restrict__ rhs, int rhs_mode,
                                                 const T* __restrict__ scal,
@@ -395,7 +403,9 @@ __global__ __launch_bounds__(TSB, CS_WPE) void k_csolve(const Desc* __restrict__
     // publish: every storing wave drains its write-through stores, the workgroup meets, one lane raises the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + it, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (fault != 0 - MMHN_COOP_FAULT=1, tests only: the first item never raises its flag, so that its dependants run into the
+    // bound of their spin and the abort path is exercised)
+    if (tid == 0 && !(fault && it == 0u)) __hip_atomic_store(flags + it, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
   }
 }

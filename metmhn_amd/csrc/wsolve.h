@@ -354,9 +354,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         pi_.droff = d.toff + rate_table_size(k) + (majP ? 0 : (1ll << __popc(d.maskP)));
         const JLink<T>& Lk = links[wd.prob];
         const int rowpart = majP ? 0 : 1;
+        long long none = -1;
+        asm volatile("" : "+v"(none));                         // (not a constant to be parked in registers over the pass loop)
         for (int q = 0; q < 2; ++q) {
           const int part = q == 0 ? rowpart : 1 - rowpart;
-          pi_.soff[q] = (TR && Lk.soff[part] >= 0) ? Lk.soff[part] + (1ll << (Lk.sk[part] - 1)) : -1;
+          pi_.soff[q] = (TR && Lk.soff[part] >= 0) ? Lk.soff[part] + (1ll << (Lk.sk[part] - 1)) : none;
           pi_.cst[q] = TR ? Lk.cst[part] : T(0);
         }
         pi_.pairRowC = wd.pairRowC; pi_.loneRowC = wd.loneRowC;
@@ -403,10 +405,13 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     // ---- state of the current window pass (per lane: the lanes of a wave differ in their patient and external index)
     // Sigma: external index (0 on a lane that is outside the pipeline), soff: byte offset of its blocks inside the chain
     // (beyond the buffer on such a lane: its stores are dropped, its loads return zeros), tbo: its patient's tables
-    uint32_t Sigma = 0, soff = OOB, tbo = L::tab0;
+    // (initial values through an opaque move: hipcc otherwise keeps the constants in registers across the chain loop and spills
+    // them)
+    auto opq = [](uint32_t v) -> uint32_t { asm volatile("" : "+v"(v)); return v; };
+    uint32_t Sigma = 0, soff = opq(OOB), tbo = L::tab0;
     T cL[WLB], dRv = T(1);
-    uint32_t hitT = 0xffffffffu, hitE = 0;
-    uint32_t rowkey = 0xffffffffu;                             // (patient, external row setting) the row constants were formed for
+    uint32_t hitT = opq(0xffffffffu), hitE = 0;
+    uint32_t rowkey = opq(0xffffffffu);                        // (patient, external row setting) the row constants were formed for
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
       const int V = sig - (TR ? WLB - __popc(ln) : __popc(ln));

@@ -789,6 +789,34 @@ def test_luad_reduced_anchor(golden):
     np.testing.assert_allclose(gr, g["indep_reg_grad"], rtol=1e-7, atol=1e-10)
 
 
+def test_cooperative_solve_spins_are_bounded(monkeypatch):
+    """csrc/tsolve.h: every wait of the one-launch tile solve is bounded.  With MMHN_COOP_FAULT=1 the first tile of every
+    cooperative launch never raises its flag: its dependants must run into the bound of their spin, set the abort word (which
+    ends every other spin at once), the launch must drain, and the host call must fail with a clear message - within seconds,
+    leaving the GPU usable: a fresh engine evaluates the same cohort correctly afterwards."""
+    import time
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 16
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 6, k=15, seed=77)                 # multi-tile joint problems on the tile route
+    lp = cref.fast_patients(lt, dp, dm, dat)[0]
+    monkeypatch.setenv("MMHN_COOP_FAULT", "1")
+    e = Engine(n)
+    e.set_cohort(dat)
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="timed out"):
+        e.patient_grads(lt, dp, dm)
+    assert time.perf_counter() - t0 < 60.0
+    e.close()
+    monkeypatch.delenv("MMHN_COOP_FAULT")
+    e = Engine(n)
+    e.set_cohort(dat)
+    r = e.patient_grads(lt, dp, dm)
+    e.close()
+    np.testing.assert_allclose(r[0], lp, rtol=1e-10)
+
+
 def test_luad28_real_workload(monkeypatch, golden):
     """The cohort examples/analysis.py of the reference really fits (`muts = list(dat.columns[1:-4])`,
     examples/analysis.py:55): ALL 28 events, 4 852 x 59 int8, 453 paired rows with k = 1 .. 21 (110 rows with k >= 13 carry 99 % of
@@ -1199,6 +1227,35 @@ def test_window_solve_lane_moves():
                     has = ((lane >> i) & 1) == (0 if tr else 1)
                     if has:
                         assert src[i, lane] == lane ^ (1 << i), (tr, i, lane, src[i, lane])
+
+
+@pytest.mark.gpu
+def test_window_kernels_against_reference_generated_vectors(monkeypatch, golden):
+    """tests/golden/large.npz - three paired rows at window shapes ((kP, kM) = (10, 5), (11, 6), (6, 11),
+    k = 16 - 18) evaluated by the REFERENCE's own source (likelihood.py:623-731 under the NumPy stand-in, tests/tools/
+    make_golden.py large).  The HIP window path (forced: MMHN_PSOLVE_MIN=1, MMHN_WSOLVE=1, buffers NaN-poisoned) must
+    reproduce them to 1e-9, and so must the tile route (MMHN_WSOLVE=0: the cooperative launch) and the level-by-level launches."""
+    import os
+    if not os.path.exists(os.path.join(GOLDEN, "large.npz")):
+        pytest.skip("large.npz not generated (tests/tools/make_golden.py large)")
+    from metmhn_amd import Engine
+    g = golden("large")
+    lt, dp, dm, dat = g["log_theta"], g["log_d_p"], g["log_d_m"], g["dat"]
+    n = (dat.shape[1] - 3) // 2
+    for env in ({"MMHN_PSOLVE_MIN": "1", "MMHN_WSOLVE": "1", "MMHN_POISON": "1"}, {"MMHN_WSOLVE": "0"},
+                {"MMHN_WSOLVE": "0", "MMHN_COOP": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        e = Engine(n)
+        e.set_cohort(dat)
+        r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], g["lp"], rtol=1e-9, err_msg=str(env))
+        np.testing.assert_allclose(r[1], g["d_th"], rtol=1e-9, atol=1e-12, err_msg=str(env))
+        np.testing.assert_allclose(r[2], g["d_dp"], rtol=1e-9, atol=1e-12, err_msg=str(env))
+        np.testing.assert_allclose(r[3], g["d_dm"], rtol=1e-9, atol=1e-12, err_msg=str(env))
+        for k_ in env:
+            monkeypatch.delenv(k_)
 
 
 @pytest.mark.gpu

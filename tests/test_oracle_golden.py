@@ -225,6 +225,30 @@ def test_luad_reduced_anchor_cpu(golden):
     np.testing.assert_allclose(np.linalg.norm(gi["indep_d_dm"]), 0.03620795819315152, rtol=1e-12)
 
 
+def test_c_ports_pinned_to_reference_at_window_shapes(golden):
+    """reference-generated vectors in the regime the headline kernels run in.  tests/golden/large.npz
+    (tests/tools/make_golden.py large) holds three paired rows, n = 12, (kP, kM) = (10, 5), (11, 6), (6, 11), orders 0 / 1 / 2,
+    k = 16 / 18 / 18, evaluated by the reference's own _g_coupled_0/1/2 (likelihood.py:623-731, through
+    regularized_optimization.score_and_grad on one-row cohorts; 15 - 70 minutes per row under the NumPy stand-in).  Both C ports -
+    the checkers of every full-size GPU test - must reproduce them to 1e-10: the chain window kernels -> metmhn_fast.c -> reference
+    is direct at these shapes."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large.npz")):
+        pytest.skip("large.npz not generated (tests/tools/make_golden.py large)")
+    from oracle import cref
+    g = golden("large")
+    lt, dp, dm, dat = g["log_theta"], g["log_d_p"], g["log_d_m"], g["dat"]
+    n = (dat.shape[1] - 3) // 2
+    kP, kM = dat[:, 0:2 * n:2].sum(1), dat[:, 1:2 * n:2].sum(1)
+    assert [(int(a), int(b)) for a, b in zip(kP, kM)] == [(10, 5), (11, 6), (6, 11)] and list(dat[:, -2]) == [0, 1, 2]
+    for name, fn in (("metmhn_ref.c", cref.patients), ("metmhn_fast.c", cref.fast_patients)):
+        lp, gth, gdp, gdm = fn(lt, dp, dm, dat)
+        np.testing.assert_allclose(lp, g["lp"], rtol=1e-10, err_msg=name)
+        np.testing.assert_allclose(gth, g["d_th"], rtol=1e-10, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(gdp, g["d_dp"], rtol=1e-10, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(gdm, g["d_dm"], rtol=1e-10, atol=1e-12, err_msg=name)
+
+
 def test_luad28_fixture_cpu(golden):
     """The 28-event LUAD cohort (examples/analysis.py:55; tests/tools/make_golden_luad.py luad28): the fixture's values come
     from oracle/metmhn_ref.c - here the second C port (metmhn_fast.c, gather formulation) reproduces the stored per-patient
