@@ -1410,8 +1410,7 @@ struct Engine : EngineBase {
     }
 #undef SP_TAIL
     if (on_side) HIPCHECK(hipEventRecord(ev_join[which], sd));
-    small_forked[which] = on_side;
-    if (which == 1) small_join(1);
+    small_forked[which] = on_side;                           // (the caller joins: small_join)
   }
   void small_join(int which) {
     if (small_forked[which]) HIPCHECK(hipStreamWaitEvent(stream, ev_join[which], 0));
@@ -1541,6 +1540,9 @@ struct Engine : EngineBase {
       if (grad) {
         if (!own_forked) staged_adj(b.stg[0]);
         staged_adj(b.stg[1]);
+        // (the 1024-thread class of the paired small-space launches ran on its side stream next to the staged kernels above:
+        // the joint adjoint is the first consumer of what it wrote)
+        small_join(1);
         if (nJ) {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
@@ -1585,7 +1587,7 @@ struct Engine : EngineBase {
         }
         // 7 assembly
       }
-      if (fused_small) small_join(0);
+      if (fused_small) { small_join(0); small_join(1); }
       if (own_forked) HIPCHECK(hipStreamWaitEvent(stream, ev_join[2], 0));
       const AsmArgs<T> aa{b.d_pats.p, b.d_dJ.p, b.d_dS.p, d_par.p, GS.p, GJ.p, gjs, dots.p, DJ.p, (long long)nJ * N, bmS.p, lp.p, N,
                           grad ? 1 : 0};
