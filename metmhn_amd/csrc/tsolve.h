@@ -49,6 +49,9 @@ struct CoopCtl {
 #ifndef MMHN_CS_WPE
 #define MMHN_CS_WPE MMHN_TS_WPE
 #endif
+#ifndef MMHN_TS_APIPE
+#define MMHN_TS_APIPE 0          // 1: step A as a software pipeline over the moves (next neighbour tile requested before the current terms)
+#endif
 #ifndef MMHN_TS_TRIP
 #define MMHN_TS_TRIP 3           // in-tile moves of a state whose LDS loads are issued together (step B)
 #endif
@@ -192,6 +195,53 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
   STAMP(2);
   wait();                                                      // (k_csolve: the tiles read below are complete and visible)
   STAMP(3);
+#if MMHN_TS_APIPE
+  // software pipeline over the moves: the neighbour tile of move i + 1 is requested before the terms of move i are formed
+  {
+    uint32_t p_mv = 0; int p_b = 0, p_kind = 0; bool p_seed = false;
+    T p_nv[NJ];
+    auto consume = [&]() {
+      const uint32_t ml = p_mv & tmask;
+      const T Lb = Ltab[p_b * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = wave + NW * j;
+        const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
+        const uint32_t x = xhi | xl;
+        const bool ss = seed_set(d, x);
+        bool cond = xl < nelem && (TR ? (xl & ml) == 0 : (xl & ml) == ml);
+        if (p_kind == 1) cond = cond && !ss && eq_noseed(d, x);
+        else if (p_seed) cond = cond && eq_noseed(d, x);
+        else cond = cond && ss;
+        const T term = Lb * Utab[p_b * 64 + (r & 63)] * p_nv[j];
+        acc[j] += cond ? term : T(0);
+      }
+    };
+    for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
+      const int c = d.cls[b];
+      const bool is_seed = joint && c == CS;
+      const bool is_pair = joint && ((d.pairP >> b) & 1u);
+      for (int kind = 0; kind < 2; ++kind) {
+        if (kind == 1 && !is_pair) continue;
+        const uint32_t mv = kind == 0 ? (1u << b) : (3u << b);
+        const uint32_t mh = mv >> t;
+        if (mh == 0) continue;
+        if (TR ? (H & mh) != 0 : (H & mh) != mh) continue;
+        T c_nv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;
+          c_nv[j] = xl < nelem ? y[base + ((xhi | xl) ^ mv)] : T(0);
+        }
+        if (p_mv) consume();
+        p_mv = mv; p_b = b; p_kind = kind; p_seed = is_seed;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) p_nv[j] = c_nv[j];
+      }
+    }
+    if (p_mv) consume();
+  }
+#else
   for (int b = (t > 0 ? t - 1 : 0); b < k; ++b) {
     const int c = d.cls[b];
     const bool is_seed = joint && c == CS;
@@ -226,6 +276,7 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
       }
     }
   }
+#endif
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const uint32_t xl = ((uint32_t)(wave + NW * j) << 6) | (uint32_t)lane;

@@ -94,6 +94,22 @@ def _grad_prim_obs(log_theta, log_d_p, state_prim, n_prim=None):
     return _eval(log_theta, log_d_p, _zeros_like_d(log_theta), _pt_row(state_prim), True)[:3]
 
 
+def _az_row(log_theta):
+    """the all-zero never-metastasised primary tumour: a type-0 row without any event (regularized_optimization.py:80-81)"""
+    n = _np.asarray(log_theta).shape[0] - 1
+    return _row(_np.zeros(2 * n + 1, dtype=_np.int8), -99, 0, n)
+
+
+def _lp_prim_obs_az(log_theta):
+    """likelihood.py:408-416: log P(00...0 | theta) = -log(1 + sum_i theta_ii), through the engine's closed-form row kind."""
+    return _eval(log_theta, _zeros_like_d(log_theta), _zeros_like_d(log_theta), _az_row(log_theta), False)
+
+
+def _grad_prim_obs_az(log_theta):
+    """likelihood.py:462-476: (log-prob, d_theta, d_dp) of the all-zero primary tumour."""
+    return _eval(log_theta, _zeros_like_d(log_theta), _zeros_like_d(log_theta), _az_row(log_theta), True)[:3]
+
+
 def _mt_row(state_mt):
     """state_mt = MT slots + seeding (= 1), length n+1 -> joint-format row of type 2."""
     st = _np.asarray(state_mt).astype(_np.int8)
