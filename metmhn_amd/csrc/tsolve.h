@@ -87,7 +87,11 @@ __device__ __forceinline__ void tsolve_tile(unsigned char* smem, const Desc* __r
   T* yt = reinterpret_cast<T*>(smem + DESC_PAD);
   T* Ltab = yt + (1 << TB);
   T* Utab = Ltab + maxk * 64;
-  const int tid = threadIdx.x;
+  // (an opaque copy of the thread id: inside k_csolve's persistent loop hipcc otherwise hoists every thread-derived index of the
+  // tile body out of the loop and spills it - 104 B of scratch per lane)
+  int tid_ = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   STAMP_DECL;                    // (-DMMHN_STAMPS: scripts/tile_stamps.py)
   STAMP_START;
   load_desc(&d, descs + prob);
