@@ -36,6 +36,10 @@
 
 namespace mmhn {
 
+#ifndef MMHN_W_CW
+#define MMHN_W_CW 0     // 1: the rates of the four wave-bit moves kept in registers with the lane-bit rates (round 4: +4 ms with the
+                        // spills of the time; re-measured in round 5 with 9 - 16 registers free)
+#endif
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS only, vector memory stays in flight
@@ -410,6 +414,9 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     auto opq = [](uint32_t v) -> uint32_t { asm volatile("" : "+v"(v)); return v; };
     uint32_t Sigma = 0, soff = opq(OOB), tbo = L::tab0;
     T cL[WLB], dRv = T(1);
+#if MMHN_W_CW
+    T cW[WWB];                                                 // rates of the four wave-bit moves (same row constants as cL)
+#endif
     uint32_t hitT = opq(0xffffffffu), hitE = 0;
     uint32_t rowkey = opq(0xffffffffu);                        // (patient, external row setting) the row constants were formed for
     auto begin_pass = [&](int sig) {
@@ -435,6 +442,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         const T r = tb[oLr + i * 64 + ln] * tb[oUr + i * 16 + wv] * tb[oEr + i * ES + Sx];
         cL[i] = has ? r : T(0);
       }
+#if MMHN_W_CW
+#pragma unroll
+      for (int j = 0; j < WWB; ++j)
+        cW[j] = tb[oLr + (WLB + j) * 64 + ln] * tb[oUr + (WLB + j) * 16 + wv] * tb[oEr + (WLB + j) * ES + Sx];
+#endif
       dRv = tab[pi_.droff + (tt | (Sx << WTB))];
       if (!TR) {
         // forward right-hand side: seeding enters row S at the one column whose paired events are those of S
@@ -542,7 +554,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
             r.q[0] = *reinterpret_cast<const u32x4*>(rs + row * QE);
             r.q[1] = *reinterpret_cast<const u32x4*>(rs + WROWS * QE + row * QE);
             const VecT nv = __builtin_bit_cast(VecT, r);
+#if MMHN_W_CW
+            const T cw = cW[j];
+#else
             const T cw = tb[oLr + (WLB + j) * 64 + ln] * tb[oUr + (WLB + j) * 16 + wv] * tb[oEr + (WLB + j) * ES + Sx];
+#endif
 #pragma unroll
             for (int c = 0; c < NC; ++c) acc[c] = fma_m(cw, nv[c], acc[c]);
           }

@@ -789,6 +789,61 @@ def test_luad_reduced_anchor(golden):
     np.testing.assert_allclose(gr, g["indep_reg_grad"], rtol=1e-7, atol=1e-10)
 
 
+def test_every_route_in_one_batch(monkeypatch):
+    """Per-problem dispatch (round 5): ONE batch in which all three joint routes and both single-tumour paths are active at
+    once - window-shaped paired rows (k = 15 .. 17; route RT_W once the thresholds are lowered), multi-tile rows outside the window
+    shapes (RT_P), rows with the seeding bit inside the tile and a few deep ones left over (RT_T, the cooperative launch), paired
+    rows whose marginal space exceeds a tile and unpaired rows of 13 - 15 bits (staged kernels, both groups) next to small ones
+    (small-space path).  Random slots, every order, every type; per-patient log-probabilities and gradients against
+    oracle/metmhn_ref.c (reference pass structure) - with the default thresholds (everything on the tile route), with the
+    thresholds at 8 (all routes), and with level-by-level launches."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 16
+    rng = np.random.default_rng(516)
+    lt, dp, dm = synthetic.random_params(n)
+    rows = []
+
+    def paired(kp, km, order):
+        r = np.zeros(2 * n + 3, dtype=np.int8)
+        r[2 * rng.choice(n, kp, replace=False)] = 1
+        r[2 * rng.choice(n, km, replace=False) + 1] = 1
+        r[2 * n], r[2 * n + 1], r[2 * n + 2] = 1, order, 3
+        return r
+
+    for i in range(12):                                          # window shapes
+        kp, km = [(10, 5), (11, 4), (4, 11), (12, 4), (5, 10), (10, 6)][i % 6]
+        rows.append(paired(kp, km, i % 3))
+    for i in range(12):                                          # multi-tile, outside the window shapes
+        kp, km = [(8, 7), (7, 7), (9, 5), (6, 8), (9, 7), (13, 2)][i % 6]
+        rows.append(paired(kp, km, [0, 1, 2, -99][i % 4]))
+    for i in range(24):                                          # small joint spaces
+        rows.append(paired(int(rng.integers(0, 6)), int(rng.integers(0, 6)), i % 3))
+    for i in range(30):                                          # unpaired rows of every type, some beyond a tile
+        typ = i % 3
+        kk = int(rng.integers(12, 15)) if i % 5 == 0 else int(rng.integers(0, 9))
+        r = np.zeros(2 * n + 3, dtype=np.int8)
+        r[2 * rng.choice(n, kk, replace=False) + (1 if typ == 2 else 0)] = 1
+        r[2 * n], r[2 * n + 1], r[2 * n + 2] = (0 if typ == 0 else 1), -99, typ
+        rows.append(r)
+    dat = np.array(rows, dtype=np.int8)
+    rng.shuffle(dat, axis=0)
+    lp, g, a, b = cref.patients(lt, dp, dm, dat)
+    for env in ({}, {"MMHN_PSOLVE_MIN": "8", "MMHN_WSOLVE_MIN": "8", "MMHN_POISON": "1"}, {"MMHN_COOP": "0", "MMHN_PSOLVE_MIN": "8"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        e = Engine(n)
+        e.set_cohort(dat)
+        r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], lp, rtol=1e-9, atol=1e-12, err_msg=str(env))
+        np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10, err_msg=str(env))
+        np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10, err_msg=str(env))
+        np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10, err_msg=str(env))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+
+
 def test_reference_name_mirrors_one_event_and_all_zero(golden):
     """VERDICT r4 missing 5: `metmhn.jx.one_event` (k = 1 paired rows) and `_lp_prim_obs_az` / `_grad_prim_obs_az`
     (likelihood.py:408-416, 462-476) by name, against the reference's values in patients.npz (the all-zero type-0 row and the
