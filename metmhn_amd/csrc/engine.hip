@@ -1248,6 +1248,14 @@ struct Engine : EngineBase {
             for (int o0 = 0; o0 < (1 << no); o0 += per) b.pcl.push_back(int4{pj, c, o0, std::min(o0 + per, 1 << no)});
           }
         }
+        // longest items first (tiles of the item = range x class blocks above the tile): the launch ends with the short ones
+        auto item_tiles = [&](const int4& it) -> long long {
+          if (it.y == 2) return 0;
+          const Desc& dj = b.dJ[it.x];
+          const int kc = popc(it.y == 0 ? dj.maskP : dj.maskM);
+          return (long long)(it.w - it.z) << (kc > PCA ? kc - PCA : 0);
+        };
+        std::stable_sort(b.pcl.begin(), b.pcl.end(), [&](const int4& x, const int4& y) { return item_tiles(x) > item_tiles(y); });
         up(b.d_pcl, b.pcl);
       }
       build_levels(b.mapS, nullptr, false, b.lmapS, b.lofS);
