@@ -36,6 +36,9 @@
 
 namespace mmhn {
 
+#ifndef MMHN_W_NTFAR
+#define MMHN_W_NTFAR -1   // >= 0: external blocks of bit >= this value are loaded with the nt policy
+#endif
 #ifndef MMHN_W_CW
 #define MMHN_W_CW 0     // 1: the rates of the four wave-bit moves kept in registers with the lane-bit rates (round 4: +4 ms with the
                         // spills of the time; re-measured in round 5 with 9 - 16 registers free)
@@ -511,9 +514,23 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       // window, the likeliest cache hit - takes the slot at the end of the step that is requested and waited for in one go
       // (forward 13.5 -> 13.1 ms per 5 000 patients; no gain in fp32 at k = 25, whose slots are all requested a phase ahead)
       auto sb = [&](int sl) -> int { return C::REV ? nX - 1 - sl : sl; };
+      // (MMHN_W_NTFAR = j0: the blocks of the external bits >= j0 - written 2^j0 window passes ago, far beyond what the XCD's L2
+      // holds for this workgroup - are loaded non-temporally, so that they do not displace the near ones; measured, section 6)
+      auto ld_ext = [&](int j) -> VecT {
+        const uint32_t off = ext_off(j);
+#if MMHN_W_NTFAR >= 0
+        if (j >= MMHN_W_NTFAR) {
+          Raw r;
+          r.q[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)boff, 2);
+          r.q[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, (int)boff, 2);
+          return __builtin_bit_cast(VecT, r);
+        }
+#endif
+        return ld_row(off, boff);
+      };
       VecT ev0, ev1;
-      if (nX > 0) ev0 = ld_row(ext_off(sb(0)), boff);
-      if (nX > 1) ev1 = ld_row(ext_off(sb(1)), boff);
+      if (nX > 0) ev0 = ld_ext(sb(0));
+      if (nX > 1) ev1 = ld_ext(sb(1));
       __builtin_amdgcn_sched_barrier(0);
       // lane moves: the neighbour lane's window slot (its previous window pass = this lane's pass)
       {
@@ -533,13 +550,13 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       if (nX > 0) ext_take(sb(0), ev0);
       if (nX > 1) ext_take(sb(1), ev1);
       if (nX > 2) {
-        ev0 = ld_row(ext_off(sb(2)), boff);
-        if (nX > 3) ev1 = ld_row(ext_off(sb(3)), boff);
+        ev0 = ld_ext(sb(2));
+        if (nX > 3) ev1 = ld_ext(sb(3));
       }
       // EV2 (transposed, five external bits - every k = 20 cohort): the fifth request goes out with the second pair into a
       // register set of its own instead of request-and-wait at the end (adjoint 14.1 -> 13.2 ms; forward 13.1 -> 13.6: off there)
       VecT ev2;
-      if constexpr (EV2) ev2 = ld_row(ext_off(sb(4)), boff);
+      if constexpr (EV2) ev2 = ld_ext(sb(4));
       __builtin_amdgcn_sched_barrier(0);
       STAMP(1);
       // wave moves: the block the neighbour wave published one step ago
@@ -570,8 +587,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         __builtin_amdgcn_sched_barrier(0);
         ext_take(sb(2), ev0);
         ext_take(sb(3), ev1);
-        ev0 = ld_row(ext_off(sb(4)), boff);
-        if (nX > 5) ev1 = ld_row(ext_off(sb(5)), boff);
+        ev0 = ld_ext(sb(4));
+        if (nX > 5) ev1 = ld_ext(sb(5));
       }
       __builtin_amdgcn_sched_barrier(0);
       STAMP(2);
@@ -600,16 +617,16 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         __builtin_amdgcn_sched_barrier(0);
         ext_take(sb(4), ev0);
         if (nX > 5) ext_take(sb(5), ev1);
-        if (nX > 6) ev0 = ld_row(ext_off(sb(6)), boff);
-        if (nX > 7) ev1 = ld_row(ext_off(sb(7)), boff);
+        if (nX > 6) ev0 = ld_ext(sb(6));
+        if (nX > 7) ev1 = ld_ext(sb(7));
       } else if (nX > 2) {
         ext_take(sb(2), ev0);
         if (nX > 3) ext_take(sb(3), ev1);
         if constexpr (EV2) ext_take(sb(4), ev2);
         else
         for (int j0 = 4; j0 < nX; j0 += 2) {                   // (spaces of more than 20 bits)
-          ev0 = ld_row(ext_off(sb(j0)), boff);
-          if (j0 + 1 < nX) ev1 = ld_row(ext_off(sb(j0 + 1)), boff);
+          ev0 = ld_ext(sb(j0));
+          if (j0 + 1 < nX) ev1 = ld_ext(sb(j0 + 1));
           ext_take(sb(j0), ev0);
           if (j0 + 1 < nX) ext_take(sb(j0 + 1), ev1);
         }
@@ -644,8 +661,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         if (nX > 6) ext_take(sb(6), ev0);
         if (nX > 7) ext_take(sb(7), ev1);
         for (int j0 = 8; j0 < nX; j0 += 2) {
-          ev0 = ld_row(ext_off(sb(j0)), boff);
-          if (j0 + 1 < nX) ev1 = ld_row(ext_off(sb(j0 + 1)), boff);
+          ev0 = ld_ext(sb(j0));
+          if (j0 + 1 < nX) ev1 = ld_ext(sb(j0 + 1));
           ext_take(sb(j0), ev0);
           if (j0 + 1 < nX) ext_take(sb(j0 + 1), ev1);
         }
