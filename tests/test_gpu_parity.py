@@ -871,6 +871,34 @@ def test_reference_name_mirrors_one_event_and_all_zero(golden):
         np.testing.assert_allclose(gdm, g[pre + "d_dm"][i], rtol=1e-10, atol=1e-13)
 
 
+def test_cooperative_launch_soak(monkeypatch, golden):
+    """A hand-off that is only wrong now and then (a stale read of another workgroup's tile under uneven load) would show as a
+    deviating evaluation: 400 evaluations of the 28-event LUAD cohort each with 37, the default (one per CU) and 1 024 workgroups -
+    fewer workgroups than tiles in flight, and more workgroups than can be resident (the queue keeps either deadlock-free) -, every
+    result against the fixture.  (`scripts/soak_coop.py` is the long form: 9 000 evaluations = 36 000 cooperative launches, all exact
+    to 2e-16 / 3e-15.)"""
+    import os
+    if not os.path.exists(os.path.join(GOLDEN, "luad28.npz")):
+        pytest.skip("luad28.npz not generated")
+    from metmhn_amd import Engine, distributed as D
+    g = golden("luad28")
+    dat, pm = g["dat"], float(g["perc_met"])
+    for wgs in ("37", None, "1024"):
+        if wgs is None:
+            monkeypatch.delenv("MMHN_COOP_WGS", raising=False)
+        else:
+            monkeypatch.setenv("MMHN_COOP_WGS", wgs)
+        e = Engine(28)
+        e.set_cohort(dat)
+        for it in range(400):
+            pt = "fit" if it & 1 else "indep"
+            s, G, a, b = D.combine_sums(e.cohort_sums(g[pt + "_theta"], g[pt + "_dp"], g[pt + "_dm"]), 29, pm)
+            assert abs(float(s) - float(g[pt + "_score"])) <= 1e-9 * abs(float(g[pt + "_score"])), (wgs, it)
+            np.testing.assert_allclose(G, g[pt + "_d_th"], rtol=1e-7, atol=1e-10, err_msg=f"workgroups {wgs} evaluation {it}")
+        e.close()
+    monkeypatch.delenv("MMHN_COOP_WGS", raising=False)
+
+
 def test_cooperative_solve_spins_are_bounded(monkeypatch):
     """csrc/tsolve.h: every wait of the one-launch tile solve is bounded.  With MMHN_COOP_FAULT=1 the first tile of every
     cooperative launch never raises its flag: its dependants must run into the bound of their spin, set the abort word (which
