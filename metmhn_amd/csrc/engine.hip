@@ -594,6 +594,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_csolve<T, true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     coop_ctl.alloc(1);
     HIPCHECK(hipMemset(coop_ctl.p, 0, sizeof(CoopCtl)));
     HIPCHECK(hipHostMalloc(reinterpret_cast<void**>(&h_abort), 64, hipHostMallocDefault));
@@ -928,6 +930,9 @@ struct Engine : EngineBase {
         if (lidg) {
           if (tr) hipLaunchKernelGGL((k_csolve<T, true, true>), CS_ARGS);
           else hipLaunchKernelGGL((k_csolve<T, false, true>), CS_ARGS);
+        } else if (coop_alone) {                               // (nothing runs beside the joint solves of this batch: 93 registers)
+          if (tr) hipLaunchKernelGGL((k_csolve<T, true, false, 4>), CS_ARGS);
+          else hipLaunchKernelGGL((k_csolve<T, false, false, 4>), CS_ARGS);
         } else {
           if (tr) hipLaunchKernelGGL((k_csolve<T, true, false>), CS_ARGS);
           else hipLaunchKernelGGL((k_csolve<T, false, false>), CS_ARGS);
@@ -957,6 +962,7 @@ struct Engine : EngineBase {
   // a spin of a cooperative launch timed out (tsolve.h): the results of the evaluation are garbage - fail the call, and put
   // the words back so that the engine stays usable.  Call after the stream has been synchronised.
   bool coop_used = false;
+  bool coop_alone = false;      // set per batch: no side stream carries whole-CU work next to the joint solves (tsolve.h: WPE)
   void check_abort() {
     if (!coop_used) return;
     coop_used = false;
@@ -1459,6 +1465,7 @@ struct Engine : EngineBase {
       const int tJ = (int)b.mapJ.size();
       const PList LJ{b.d_dJ.p, b.d_mapJ.p, tJ, b.maxkJ, b.vecJ, b.d_lmapJ.p, &b.lofJ, tabJ.p};       // (Jacobi solver only)
       const bool fused_small = b.has_small, staged = !b.stg[0].empty() || !b.stg[1].empty();
+      coop_alone = b.stg[0].empty();                          // (no second cooperative launch on a side stream next to the joint solves)
       // the staged kernels of one group of patients (Batch::stg): forward part (tables, right-hand sides, 1/diag, forward solve,
       // scores and adjoint seeds) and gradient part (adjoint solve, gradient rows, observation-rate marginals)
       auto staged_fwd = [&](const Staged& g) {

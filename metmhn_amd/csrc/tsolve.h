@@ -385,8 +385,13 @@ __global__ __launch_bounds__(TSB, TS_WPE) void k_tsolve(const Desc* __restrict__
 //   items / deps: the work list of this direction;  flags[i] == epoch: item i of this launch is stored and visible;
 //   ctl->head[slot]: queue head;  h_abort: the pinned host copy of ctl->abort;  fault: test hook (see the publish step).
 // ------------------------------------------------------------------------------------
-template <typename T, bool TR, bool LIDGV>
-__global__ __launch_bounds__(TSB, CS_WPE) void k_csolve(const Desc* __restrict__ descs,
+// WPE: waves per SIMD the registers are sized for.  8 (64 registers; 80 - 104 B per lane of scratch: the persistent loop keeps the
+// kernel arguments live) lets a CU hold this workgroup AND a 1 024-thread workgroup of another stream - the small-space launches and
+// the staged own-problem chain that run next to the joint solves of a heterogeneous cohort (28-event LUAD cohort: 1.41 against 1.56 ms);
+// 4 (93 registers, no scratch) is faster when nothing runs beside it (LUAD-reduced cohort: 0.339 against 0.350 ms).  The engine picks
+// per batch (Engine::solve).
+template <typename T, bool TR, bool LIDGV, int WPE = CS_WPE>
+__global__ __launch_bounds__(TSB, WPE) void k_csolve(const Desc* __restrict__ descs,
                                                 const CItem* __restrict__ items, const int* __restrict__ deps, int nitems,
                                                 unsigned* flags, unsigned epoch, CoopCtl* ctl, int slot, unsigned* h_abort, int fault,
                                                 T* y, const T* __restrict__ lidg,
