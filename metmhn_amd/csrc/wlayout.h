@@ -59,8 +59,11 @@ template <typename T> struct WCfg;
 #ifndef MMHN_WHB
 #define MMHN_WHB 2    // build switch (experiments): log2 of the blocks of a window, fp64
 #endif
+#ifndef MMHN_WNXT_D
+#define MMHN_WNXT_D (7 - MMHN_WHB)   // build switch (experiments): -2 = every fp64 chain on the generic instantiation
+#endif
 template <> struct WCfg<double> {
-  static constexpr int RB = 2, HB = MMHN_WHB, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = 7 - MMHN_WHB;
+  static constexpr int RB = 2, HB = MMHN_WHB, KC = 9, KR = 15, KE = 9, PAD = 2, NXT = MMHN_WNXT_D;
   static constexpr bool FACT = false, REV = true, ON = true;
 };
 #ifndef MMHN_WF32

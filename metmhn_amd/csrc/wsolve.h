@@ -39,6 +39,21 @@ namespace mmhn {
 #ifndef MMHN_W_NTFAR
 #define MMHN_W_NTFAR -1   // >= 0: external blocks of bit >= this value are loaded with the nt policy
 #endif
+// Round-5 switches, all measured and left off: none of them moves a launch by more than the noise - the
+// launch moves its 3.84 units of a patient's seeded half at the rate HBM delivers, whatever the order inside a step
+#ifndef MMHN_W_WPERM
+#define MMHN_W_WPERM 0  // 1: the wave index of the rows comes from a permutation of the hardware wave id that gives each SIMD (hardware
+                        // waves s, s + 4, s + 8, s + 12) the same number of ring moves (8 of the 32 of a step)
+#endif
+#ifndef MMHN_W_PRIO
+#define MMHN_W_PRIO 0   // 1: issue priority of a wave = its wave-level (the wave with the most ring moves is the one a barrier waits for)
+#endif
+#ifndef MMHN_W_STAG
+#define MMHN_W_STAG 0   // 1: the second external request of a step goes out half-way down the lane moves
+#endif
+// Timing-only ablations (WRONG results): MMHN_WABL_NOLOAD / _NOSTORE (no external block read / nothing written),
+// _NOTAB (no table read in a step), _NOPERM (the two lane exchanges of the LDS crossbar as DPP moves), _NORING (no ring reads),
+// _NOBAR (no barrier in the step loop)
 #ifndef MMHN_W_CW
 #define MMHN_W_CW 0     // 1: the rates of the four wave-bit moves kept in registers with the lane-bit rates (round 4: +4 ms with the
                         // spills of the time; re-measured in round 5 with 9 - 16 registers free)
@@ -46,7 +61,9 @@ namespace mmhn {
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS only, vector memory stays in flight
+#ifndef MMHN_WABL_NOBAR
   __builtin_amdgcn_s_barrier();
+#endif
 }
 
 template <typename T> __device__ __forceinline__ T fma_m(T a, T b, T c);
@@ -208,12 +225,27 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   T* const thc = lds + L::thc;
   T* const e0 = lds + L::e0;
   WPInfo<T>* const pinfo = reinterpret_cast<WPInfo<T>*>(lds + L::end);
+#if MMHN_W_WPERM
+  // hardware wave -> wave index of its rows (nibble h of the constant, from the top)
+  const int wv = __builtin_amdgcn_readfirstlane((int)((0x0123FEDC5647A9B8ull >> (60 - 4 * ((int)threadIdx.x >> 6))) & 15ull));
+  const int tid = (wv << 6) | ((int)threadIdx.x & 63);
+#else
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int lam = TR ? WWB - __popc(wv) : __popc(wv);          // wave-level: blocks this wave runs behind
+#if MMHN_W_PRIO
+  if (lam >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (lam == 2) __builtin_amdgcn_s_setprio(2);
+  else if (lam == 1) __builtin_amdgcn_s_setprio(1);
+#endif
   // (thread-derived values are re-derived from an opaque copy of the thread id inside every step / pass: hipcc would
   // otherwise hoist a dozen loop-invariant LDS addresses out of the step loop and spill them)
+#if MMHN_W_WPERM
+  auto opaque_tid = [&]() -> uint32_t { uint32_t t = (uint32_t)threadIdx.x & 63u; asm volatile("" : "+v"(t)); return t | ((uint32_t)wv << 6); };
+#else
   auto opaque_tid = [&]() -> uint32_t { uint32_t t = (uint32_t)threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+#endif
   // a column set that does not contain bit b, with bit b squeezed out
   auto squeeze = [](uint32_t v, int b) -> uint32_t { return ((v >> (b + 1)) << b) | (v & ((1u << b) - 1u)); };
   auto deskew = [&]() { for (int s = lam; s < WWB; ++s) lds_barrier(); };
@@ -395,6 +427,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       __builtin_amdgcn_raw_buffer_store_b128(r.q[1], rsrc, (int)off + 16, (int)soff, 0);
     };
     auto lds_vec = [&](const T* p) -> VecT {                   // NC consecutive elements, 16-byte aligned
+#ifdef MMHN_WABL_NOTAB
+      VecT cv;
+      for (int c = 0; c < NC; ++c) cv[c] = T(0.25);
+      return cv;
+#endif
       Raw r;
       r.q[0] = *reinterpret_cast<const u32x4*>(p);
       r.q[1] = *reinterpret_cast<const u32x4*>(p + QE);
@@ -505,7 +542,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
           }
         } else {
           const int i = WTB + (j - nXc);
+#ifdef MMHN_WABL_NOTAB
+          const T r = T(0.125);
+#else
           const T r = tb[oLr + i * 64 + ln] * tb[oUr + i * 16 + wv] * tb[oEr + i * ES + Sx];
+#endif
 #pragma unroll
           for (int c = 0; c < NC; ++c) acc[c] = fma_m(r, nv[c], acc[c]);
         }
@@ -530,19 +571,33 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
       };
       VecT ev0, ev1;
       if (nX > 0) ev0 = ld_ext(sb(0));
+#if !MMHN_W_STAG
       if (nX > 1) ev1 = ld_ext(sb(1));
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // lane moves: the neighbour lane's window slot (its previous window pass = this lane's pass)
       {
         const VecT old = Wd[beta];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+#if MMHN_W_STAG
+          if (c == NC / 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (nX > 1) ev1 = ld_ext(sb(1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
           acc[c] = fma_m(cL[0], lane_nbr<0, TR>(old[c], (int)ln), acc[c]);
           acc[c] = fma_m(cL[1], lane_nbr<1, TR>(old[c], (int)ln), acc[c]);
           acc[c] = fma_m(cL[2], lane_nbr<2, TR>(old[c], (int)ln), acc[c]);
           acc[c] = fma_m(cL[3], lane_nbr<3, TR>(old[c], (int)ln), acc[c]);
+#ifdef MMHN_WABL_NOPERM
+          acc[c] = fma_m(cL[4], lane_nbr<3, TR>(old[c], (int)ln), acc[c]);
+          acc[c] = fma_m(cL[5], lane_nbr<2, TR>(old[c], (int)ln), acc[c]);
+#else
           acc[c] = fma_m(cL[4], lane_nbr<4, TR>(old[c], (int)ln), acc[c]);
           acc[c] = fma_m(cL[5], lane_nbr<5, TR>(old[c], (int)ln), acc[c]);
+#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -564,7 +619,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         const T* rs = ring + (uint32_t)(gpar ^ 1) * (NC * WROWS);
 #pragma unroll
         for (int j = 0; j < WWB; ++j) {
+#ifdef MMHN_WABL_NORING
+          const bool has = false;
+#else
           const bool has = TR ? !((wv >> j) & 1) : ((wv >> j) & 1);
+#endif
           if (has) {                                           // wave-uniform
             const uint32_t row = tt ^ (64u << j);
             Raw r;
@@ -573,6 +632,8 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
             const VecT nv = __builtin_bit_cast(VecT, r);
 #if MMHN_W_CW
             const T cw = cW[j];
+#elif defined(MMHN_WABL_NOTAB)
+            const T cw = T(0.125);
 #else
             const T cw = tb[oLr + (WLB + j) * 64 + ln] * tb[oUr + (WLB + j) * 16 + wv] * tb[oEr + (WLB + j) * ES + Sx];
 #endif
@@ -676,6 +737,9 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         for (int r = 0; r < RB; ++r) fxr[r] = tb[oFx + r * XS + Tx];
       }
       auto blk_rate = [&](int r, int wset, int wsq) -> T {     // rate of column bit r at window setting wset (bit r clear)
+#ifdef MMHN_WABL_NOTAB
+        return T(0.125);
+#endif
         if constexpr (C::FACT) return tb[L::oFw + r * WIN + wset] * fxr[r];
         else return tb[L::oRh + r * SZLO + Tx * LOS + wsq];
       };
