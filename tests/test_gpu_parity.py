@@ -1117,6 +1117,38 @@ def _one_rank_comm(e):
 
 
 @pytest.mark.gpu
+def test_full_size_gradient_is_directional_difference_of_score():
+    """The reference's own test strategy (tests/test_gradient.py:9-31,68-69: analytic gradient of score_and_grad against finite
+    differences of score) at the headline size, where no oracle finishes in seconds: 320 paired patients with n = k = 20 of every
+    order - the window route of the engine (forward solve, adjoint solve, class marginals, gradient rows) - and 64 rows of mixed types
+    (PT-only, MT-only, never-metastasising, paired with fewer events: the tile and small-space routes, EM and NM rows weighted by
+    perc_met), the regularised objective and its gradient through the reference's entry points, central differences of score_reg
+    along four random directions of the 440-dimensional parameter vector (h = 1e-5: truncation ~1e-10, rounding ~1e-11 relative)."""
+    from metmhn_amd import regularized_optimization as ro, synthetic
+    n = 20
+    lt, dp, dm = synthetic.random_params(n)
+    dat = np.vstack((np.asarray(synthetic.full_k_cohort(n, 320, seed=77)), np.asarray(synthetic.mixed_cohort(n, 64, seed=3, p_event=0.3))))
+    assert {0, 1, 2, 3} <= set(int(t) for t in dat[:, -1])
+    params = np.concatenate((np.asarray(lt).flatten(), dp, dm))
+    v, g = ro.score_and_grad_reg(params, dat, 0.3, ro.symmetric_penal, 1e-2)
+    assert np.isfinite(v) and np.isfinite(g).all()
+    rng = np.random.default_rng(5)
+    h = 1e-5
+    for _ in range(4):
+        u = rng.standard_normal(params.size)
+        u /= np.linalg.norm(u)
+        fd = (float(ro.score_reg(params + h * u, dat, 0.3, ro.symmetric_penal, 1e-2))
+              - float(ro.score_reg(params - h * u, dat, 0.3, ro.symmetric_penal, 1e-2))) / (2 * h)
+        np.testing.assert_allclose(float(g @ u), fd, rtol=2e-6, atol=1e-9)
+    # one coordinate of each block, the reference's forward difference (h = 1e-8, rtol 1e-4)
+    for idx in (3 * (n + 1) + 7, (n + 1) ** 2 + 4, (n + 1) ** 2 + (n + 1) + 9):
+        e = np.zeros(params.size)
+        e[idx] = 1e-8
+        fd = (float(ro.score_reg(params + e, dat, 0.3, ro.symmetric_penal, 1e-2)) - float(v)) / 1e-8
+        np.testing.assert_allclose(g[idx], fd, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
 def test_config3_rank_shard_n20_50000_patients():
     """BASELINE configs[3] (n = 20, 50 000 patients over 8 GPUs) as ONE rank sees it: the LPT shard 0 of the 50 000-row
     cohort (6 250 rows, regularized_optimization.py:256-266 is what shards), evaluated through the pre-combined
