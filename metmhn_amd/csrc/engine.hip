@@ -153,6 +153,7 @@ struct Batch {
   std::vector<WDesc> wd;         // sorted by shape; the state vectors of consecutive entries lie back to back
   DevArr<WDesc> d_wd;
   int wnx = -1;                  // external bits of every window problem of the batch, -1: they differ
+  bool wsplit = false;           // this batch runs the window route with two workgroups per patient (MMHN_WSPLIT)
   std::vector<WChain> wchains;   // runs of same-shape entries, one workgroup each (wsolve.h)
   DevArr<WChain> d_wchains;
   long long offT = 0;            // the RT_T problems' vectors start here (the tile solver skips their dead tiles: kept zero)
@@ -521,6 +522,9 @@ struct Engine : EngineBase {
   unsigned* h_abort_dev = nullptr;
   int wsolve_chain = 1;         // MMHN_WSOLVE_CHAIN=0: every window problem its own chain (the pipeline drains between patients)
   int wsolve_wgs = 0;           // MMHN_WSOLVE_WGS: workgroups of the window solve (default: one per CU)
+  bool wsplit = false;          // MMHN_WSPLIT=1: two workgroups per patient on the window route (wsolve.h: SPLIT; measured, off)
+  DevArr<unsigned> wprog;       // ... the progress words of its pairs
+  unsigned wsplit_epoch = 0;
   int wsolve_mode = 1;          // joint solves of per-patient batches in the window layout (wsolve.h); MMHN_WSOLVE=0: the tile
                                 // kernels (k_psolve2) for every problem, 2: window solves converted back to index order
   DevArr<T> piM, qM;            // matrix / window path: solutions in their own layout
@@ -578,6 +582,7 @@ struct Engine : EngineBase {
       if (const char* sp = std::getenv("MMHN_PREP_SPLIT")) prep_split_max = std::atoi(sp);
       if (const char* ms = std::getenv("MMHN_WSOLVE")) wsolve_mode = std::atoi(ms);
       if (const char* ms = std::getenv("MMHN_WSOLVE_WGS")) wsolve_wgs = std::atoi(ms);
+      if (const char* ms = std::getenv("MMHN_WSPLIT")) wsplit = std::atoi(ms) != 0;
       if (const char* ms = std::getenv("MMHN_WSOLVE_CHAIN")) wsolve_chain = std::atoi(ms);
       hipDeviceProp_t prop;
       HIPCHECK(hipGetDeviceProperties(&prop, device));
@@ -587,6 +592,8 @@ struct Engine : EngineBase {
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false, WCfg<T>::NXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true, WCfg<T>::NXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, false, WCfg<T>::NXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
+    HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wsolve<T, true, WCfg<T>::NXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsolve_lds<T>()));
     HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wclass<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wclass_lds<T>()));
     // kernels may need more than the default dynamic LDS window
     const int lds = 150 * 1024;
@@ -832,6 +839,8 @@ struct Engine : EngineBase {
   size_t psolve2_lds(int maxk) const {
     return DESC_PAD + ((size_t)(1 << TB) + (size_t)((1 << TB) / TSB) + 3 * (size_t)maxk * 64 + (size_t)maxk * maxk + maxk) * sizeof(T) + 400 * sizeof(uint32_t) + (size_t)TSB * sizeof(uint16_t);
   }
+  // groups of chains under MMHN_WSPLIT (a multiple of eight: the pair of a block is the block eight further on)
+  int wsplit_groups() const { return std::max(8, (wsolve_wgs > 0 ? wsolve_wgs : n_cu) / 16 * 8); }
   // the joint solves of a batch, every problem on its route (Batch::route)
   void psolve(bool tr, const Batch& b, T* y, int rhs_mode) {
     const int nJ = (int)b.dJ.size();
@@ -846,10 +855,25 @@ struct Engine : EngineBase {
         const int nch = (int)b.wchains.size();
         const dim3 g((unsigned)std::min(nch, wsolve_wgs > 0 ? wsolve_wgs : n_cu)), bk(WROWS);
         const size_t lds = wsolve_lds<T>();
-#define WS_ARGS g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p
+#define WS_ARGS g, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p, (unsigned*)nullptr, 0u, (unsigned*)nullptr, (unsigned*)nullptr
         // (a batch whose chains all have the same number of external bits - every k = 20 cohort: 5, k = 25: 9 - runs the instantiation
         // that knows it at compile time)
-        if (b.wnx == WCfg<T>::NXT) { if (tr) hipLaunchKernelGGL((k_wsolve<T, true, WCfg<T>::NXT>), WS_ARGS); else hipLaunchKernelGGL((k_wsolve<T, false, WCfg<T>::NXT>), WS_ARGS); }
+        if (b.wsplit) {
+          // two workgroups per patient: pairs (b, b + 8) walk the chains dealt to wsplit_groups() groups
+          const int npairs = std::min((nch + 7) / 8 * 8, wsplit_groups());
+          if (wprog.n < (size_t)npairs) { wprog.alloc((size_t)wsplit_groups() + 64); wsplit_epoch = 0; }
+          if (wsplit_epoch == 0 || wsplit_epoch >= 2047u) {
+            HIPCHECK(hipMemsetAsync(wprog.p, 0, wprog.n * sizeof(unsigned), stream));
+            wsplit_epoch = 0;
+          }
+          ++wsplit_epoch;
+          coop_used = true;
+          const dim3 g2((unsigned)(2 * npairs));
+#define WS2_ARGS g2, bk, lds, stream, b.d_dJ.p, b.d_wd.p, b.d_wchains.p, nch, yw, tabJ.p, links.p, qS.p, wprog.p, wsplit_epoch << 20, &coop_ctl.p->abort, h_abort_dev
+          if (tr) hipLaunchKernelGGL((k_wsolve<T, true, WCfg<T>::NXT, true>), WS2_ARGS);
+          else hipLaunchKernelGGL((k_wsolve<T, false, WCfg<T>::NXT, true>), WS2_ARGS);
+#undef WS2_ARGS
+        } else if (b.wnx == WCfg<T>::NXT) { if (tr) hipLaunchKernelGGL((k_wsolve<T, true, WCfg<T>::NXT>), WS_ARGS); else hipLaunchKernelGGL((k_wsolve<T, false, WCfg<T>::NXT>), WS_ARGS); }
         else if (tr) hipLaunchKernelGGL((k_wsolve<T, true>), WS_ARGS);
         else hipLaunchKernelGGL((k_wsolve<T, false>), WS_ARGS);
 #undef WS_ARGS
@@ -1168,7 +1192,8 @@ struct Engine : EngineBase {
         const int nW = (int)b.wd.size();
         b.wnx = b.wd[0].nXc + b.wd[0].nXr;
         for (const WDesc& w : b.wd) if (w.nXc + w.nXr != b.wnx) b.wnx = -1;
-        const int groups = std::max(1, wsolve_wgs > 0 ? wsolve_wgs : n_cu);
+        b.wsplit = wsplit && b.wnx == WCfg<T>::NXT && WCfg<T>::NXT >= 4;
+        const int groups = b.wsplit ? wsplit_groups() : std::max(1, wsolve_wgs > 0 ? wsolve_wgs : n_cu);
         const int per = (nW + groups - 1) / groups;
         for (int i0 = 0; i0 < nW;) {
           const WDesc& w = b.wd[i0];

@@ -200,11 +200,22 @@ constexpr size_t wsolve_lds() { return WLds<T>::bytes; }
 // ------------------------------------------------------------------------------------
 // NXT >= 0: the number of external bits of every chain of the launch, as a compile-time constant (the step loop then has no
 // scalar branches on it); NXT < 0: read per chain
-template <typename T, bool TR, int NXT = -1>
+// SPLIT (NXT >= 4): TWO workgroups per patient (review item 2 of round 4 in its cheapest form).  Blocks b and
+// b + 8 - the same XCD under the round-robin placement of workgroups - are a pair that walks the same chains: role 0 ("A") takes the
+// half of every patient's passes it does not need the partner for (forward: top bit of the external index clear; transposed: set),
+// role 1 ("B") the other half, whose move along the top bit reads what A wrote.  A lane of B at pass g needs the SAME lane of A at
+// pass g, i.e. A's iteration of the same number: A drains its stores at the end of every iteration of the pass loop and its last wave
+// raises the pair's progress word (write-through stores, relaxed agent-scope flag: the protocol of k_csolve, tsolve.h); every wave of B
+// polls that word in front of an iteration (bounded; `abort_w` / `h_abort` as in k_csolve), one agent-scope acquire, plain loads.
+// Every workgroup sets the patient's tables up; the transposed solve's seed = 0 lattice is B's.
+constexpr unsigned WSPLIT_SPIN_LIMIT = 1u << 22;
+template <typename T, bool TR, int NXT = -1, bool SPLIT = false>
 __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs, const WDesc* __restrict__ wds,
                                                   const WChain* __restrict__ chains, int nchains,
                                                   T* y, const T* __restrict__ tab,
-                                                  const JLink<T>* __restrict__ links, const T* __restrict__ qS) {
+                                                  const JLink<T>* __restrict__ links, const T* __restrict__ qS,
+                                                  unsigned* wprog, unsigned wbase, unsigned* abort_w, unsigned* h_abort) {
+  static_assert(!SPLIT || NXT >= 4, "two workgroups per patient: a compile-time number of external bits, 2^(NXT - 1) > 6 passes per half");
   using C = WCfg<T>;
   using L = WLds<T>;
   constexpr int RB = C::RB, HB = C::HB, NC = 1 << RB, H = 1 << HB, WB = RB + HB, WIN = 1 << WB;
@@ -254,7 +265,35 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
   // (formed once: inside the chain loop the addresses of wrho's tables were kept over the step loop and spilled)
   const uint32_t voff = wrho((uint32_t)tid >> 6, (uint32_t)tid & 63u) * (uint32_t)sizeof(VecT);
   STAMP_DECL;
-  for (int ci = blockIdx.x; ci < nchains; ci += gridDim.x) {
+  // SPLIT: pair and role of this workgroup; cum = iterations of the pass loop the pair has behind it in this launch
+  const int role = SPLIT ? (int)((blockIdx.x >> 3) & 1u) : 0;
+  const int cstart = SPLIT ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u)) : (int)blockIdx.x;
+  const int cstep = SPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  unsigned* const prog = SPLIT ? wprog + cstart : nullptr;
+  unsigned cum = 0;
+  // B: wait until A has `need` iterations behind it (every wave by itself: no barrier; one acquire)
+  auto wait_partner = [&](unsigned need) {
+    const unsigned want = wbase + need;
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned v = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(v - want) >= 0) break;
+      if ((++spins & 15u) == 0u) {
+        if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (spins > WSPLIT_SPIN_LIMIT) {
+          __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(h_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+#ifndef MMHN_WSPLIT_NOACQ   // (experiment, timing only)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  };
+  for (int ci = cstart; ci < nchains; ci += cstep) {
     STAMP_START;
     const int first = sgpr(chains[ci].start), npat = sgpr(chains[ci].count);
     if (npat == 0) continue;                                   // (a filler entry of the host's chain deal)
@@ -274,9 +313,11 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     const long long half = 1ll << (k - 1);
     const long long ybase = sgpr64(d0.off);                    // patient j of the chain: y + ybase + (j << k)
     const uint32_t NXS = 1u << nX, mXc = (1u << nXc) - 1u;
+    const int nXw = SPLIT ? nX - 1 : nX;                       // log2 of the passes of a patient THIS workgroup makes
+    const uint32_t NXW = 1u << nXw;
     const uint32_t Sxfull = (1u << nXr) - 1u, Txfull = mXc;
     const uint32_t PATB = (uint32_t)(sizeof(T) << k), HALFB = PATB >> 1;   // bytes of a patient's vector / of its seeded half
-    const int NPASS = npat * (int)NXS + WLB;
+    const int NPASS = npat * (int)NXW + WLB;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(sgpr64((long long)reinterpret_cast<char*>(y + ybase))), 0,
                                                         (int)sgpr((uint32_t)npat * PATB), 0x00020000);
     // ---- a patient enters: its tables (buffer j & 1), forward: its seed = 0 lattice (only PT == MT states carry values).
@@ -423,8 +464,13 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     };
     auto st_row = [&](uint32_t off, uint32_t soff, const VecT& v) {
       const Raw r = __builtin_bit_cast(Raw, v);
-      __builtin_amdgcn_raw_buffer_store_b128(r.q[0], rsrc, (int)off, (int)soff, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(r.q[1], rsrc, (int)off + 16, (int)soff, 0);
+#ifdef MMHN_WSPLIT_PLAIN   // (experiment: plain stores - only valid while both workgroups of a pair sit on one XCD)
+      constexpr int WT = 0;
+#else
+      constexpr int WT = SPLIT ? 16 : 0;                        // (16: sc1, write-through)
+#endif
+      __builtin_amdgcn_raw_buffer_store_b128(r.q[0], rsrc, (int)off, (int)soff, WT);
+      __builtin_amdgcn_raw_buffer_store_b128(r.q[1], rsrc, (int)off + 16, (int)soff, WT);
     };
     auto lds_vec = [&](const T* p) -> VecT {                   // NC consecutive elements, 16-byte aligned
 #ifdef MMHN_WABL_NOTAB
@@ -462,9 +508,9 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     auto begin_pass = [&](int sig) {
       const uint32_t tt = opaque_tid(), ln = tt & 63u;
       const int V = sig - (TR ? WLB - __popc(ln) : __popc(ln));
-      const bool act = (unsigned)V < (unsigned)npat * NXS;
+      const bool act = (unsigned)V < (unsigned)npat * NXW;
       const uint32_t Vc = act ? (uint32_t)V : 0u;
-      const uint32_t j = Vc >> nX, g = Vc & (NXS - 1u);
+      const uint32_t j = Vc >> nXw, g = (Vc & (NXW - 1u)) | (SPLIT ? (uint32_t)role << nXw : 0u);
       Sigma = TR ? NXS - 1u - g : g;
       const uint32_t Sx = Sigma >> nXc;
       tbo = L::tab0 + (j & 1u) * L::TABSZ;
@@ -790,10 +836,12 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
     // a patient enters every 2^nX passes (the waves meet for its tables: four steps of slack) and, transposed, is
     // completed by its seed = 0 lattice six passes after the next one entered
     for (int sig = 0; sig < NPASS; ++sig) {
-      const uint32_t ph = (uint32_t)sig & (NXS - 1u);
-      const int jj = sig >> nX;
+      const uint32_t ph = (uint32_t)sig & (NXW - 1u);
+      const int jj = sig >> nXw;
       if (ph == 0 && jj >= 1 && jj < npat) { deskew(); enter(jj); reskew(); }
-      if (TR && ph == (uint32_t)WLB && jj >= 1) { deskew(); leave(jj - 1); reskew(); }
+      // SPLIT: B needs A's iteration of the same number (A's word counts the iterations it has drained)
+      if constexpr (SPLIT) { if (role == 1) wait_partner(cum + (unsigned)sig + 1u); }
+      if (TR && ph == (uint32_t)WLB && jj >= 1 && !(SPLIT && role == 0)) { deskew(); leave(jj - 1); reskew(); }
  STAMP(7);
       begin_pass(sig);
       STAMP(6);
@@ -811,9 +859,24 @@ __global__ __launch_bounds__(WROWS) void k_wsolve(const Desc* __restrict__ descs
         step(IC<7 % H>{}, g0 ^ 1); lds_barrier(); STAMP(5);
       }
       static_assert(H == 2 || H == 4 || H == 8, "window of 2, 4 or 8 blocks");
+      if constexpr (SPLIT) {
+        // A: this wave's stores up to here are complete; the wave that runs furthest behind (every other one passed this point
+        // before it) raises the pair's word
+        if (role == 0) {
+#ifndef MMHN_WSPLIT_NODRAIN  // (experiment, timing only)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+          if (lam == WWB && (threadIdx.x & 63u) == 0u)
+            __hip_atomic_store(prog, wbase + cum + (unsigned)sig + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if constexpr (SPLIT) {
+      if (role == 1) wait_partner(cum + (unsigned)NPASS);      // (the transposed solve's last lattice reads A's half too)
+      cum += (unsigned)NPASS;
     }
     deskew();
-    if (TR) leave(npat - 1);
+    if (TR && !(SPLIT && role == 0)) leave(npat - 1);
     __syncthreads();
     STAMP(7);
   }

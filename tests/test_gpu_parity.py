@@ -1477,6 +1477,37 @@ def test_window_layout_solves_match_cpu_port(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_window_route_two_workgroups_per_patient(monkeypatch):
+    """MMHN_WSPLIT=1 (csrc/wsolve.h, SPLIT; measured slower and off by default - DESIGN.md section 6): a patient's passes split on the top
+    bit of the external index between two workgroups, the second one reading the first one's half behind a progress word.  n = k = 20
+    patients of every order against oracle/metmhn_fast.c, with eight pairs (chains of two patients, both table buffers of both
+    workgroups in use) and with one pair per patient; NaN-poisoned vectors."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 20
+    lt, dp, dm = synthetic.random_params(n)
+    dat = synthetic.full_k_cohort(n, 16, seed=2000 + n)
+    lp, g, a, b = cref.fast_patients(lt, dp, dm, dat)
+    monkeypatch.setenv("MMHN_WSPLIT", "1")
+    monkeypatch.setenv("MMHN_PSOLVE_MIN", "1")
+    monkeypatch.setenv("MMHN_POISON", "1")
+    for wgs in ("16", None):
+        if wgs is None:
+            monkeypatch.delenv("MMHN_WSOLVE_WGS", raising=False)
+        else:
+            monkeypatch.setenv("MMHN_WSOLVE_WGS", wgs)
+        e = Engine(n)
+        e.set_cohort(dat)
+        for _ in range(2):                                      # (the second evaluation meets the progress words of the first)
+            r = e.patient_grads(lt, dp, dm)
+        e.close()
+        np.testing.assert_allclose(r[0], lp, rtol=1e-10)
+        np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_window_path_fp32_k25_shapes(monkeypatch):
     """The fp32 window path (BASELINE configs[4]: k = 25, nine external bits): column-class rates as two factors in LDS
     (csrc/wsolve.h, WCfg<float>::FACT), tables packed per shape, up to 12 column bits, 18 row bits, 12 paired events.
