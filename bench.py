@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the engine's four streams on hardware queues of their own: metmhn_amd/_lib.py sets the same default when it loads the library;
+# here it is in place before anything can have initialised the HIP runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r5_traffic.json")
@@ -465,6 +468,7 @@ def main():
                        "parallelism": f"patient-shard x{world}, one RCCL all-reduce of {1 + N * N + 2 * N} f64 per eval (EM / NM pre-combined on the device) "
                                       f"({'inside the library on the engine stream' if getattr(eng, '_device_comm', False) else 'none (1 rank)' if world == 1 else 'torch.distributed'})",
                        "rccl_ranks": cnt.get("comm_ranks", 0), "rccl_rank": cnt.get("comm_rank", -1), "shards": shard,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "solver": os.environ.get("MMHN_SOLVER", "substitution, per-problem dispatch (k_wsolve: window layout, chains of patients; k_psolve2: one workgroup "
                                                                "per patient; k_csolve: all remaining tiles in one cooperative launch)"),
                        "objective_value": float(val), "grad_norm": float(np.linalg.norm(grad))},

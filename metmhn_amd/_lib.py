@@ -118,6 +118,13 @@ def load():
     # must not end up with two HIP runtimes: if this library came first (bound to /opt/rocm's copy), a later
     # `import torch` + torch.cuda / RCCL initialisation fails with "No HIP GPUs are available".  So when torch is
     # installed it is imported first and both sides share its runtime (same sonames; the order bench.py always had).
+    # An engine issues an evaluation on four streams (joint path; the paired rows' 1024-thread small-space launch the joint adjoint
+    # waits for; the own-problem rows' small-space launches; their staged chain).  The HIP runtime spreads a process's streams over
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that land on one queue run in order: on the 28-event LUAD cohort the
+    # paired launch then queues behind the own-problem chain - 1.42 instead of 1.25 ms per evaluation in a fresh process (DESIGN.md
+    # section 6).  Read when the runtime initialises, so it is set here, before the first HIP call of a typical process; a value the
+    # user exported wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import sys
     if "torch" not in sys.modules:
         try:

@@ -24,7 +24,10 @@ for r in rows[first:last]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"].replace("mmhn::", "").replace("void ", "")
     name = name[:name.index("(")] if "(" in name else name
-    print(f"{(s - t0) / 1e3:10.1f} us  {(e - s) / 1e3:10.1f} us  gap {(s - prev_end) / 1e3:8.1f}  {name[:70]}")
+    wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)
+    grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+    shape = f"{grid // wg if wg else 0:6d} x {wg:4d}"
+    print(f"{(s - t0) / 1e3:10.1f} us  {(e - s) / 1e3:10.1f} us  gap {(s - prev_end) / 1e3:8.1f}  {shape}  q{r.get('Queue_Id', '?')}  {name[:70]}")
     busy += e - s
     prev_end = max(prev_end, e)
 print(f"span {(prev_end - t0) / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us")
