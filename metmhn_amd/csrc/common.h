@@ -92,11 +92,18 @@ __host__ __device__ inline long long table_size(const Desc& d) {
   return s;
 }
 
-template <typename T, bool SPLIT = false>
-__global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
+template <typename T>
+inline size_t prep_lds(int N) { return (size_t)(N + 1) * 192 * sizeof(T); }
+// PB: threads of a workgroup (1 024 on the long launches: the kernel is a chain of short phases between barriers - waves to hide
+// them behind, at the same LDS per workgroup; the SPLIT launches of short cohorts keep 256)
+template <typename T, bool SPLIT = false, int PB = BLOCK>
+__global__ __launch_bounds__(PB) void k_prep(const Desc* __restrict__ descs,
                                                 const Params<T>* __restrict__ par, T* tab, const int* __restrict__ plist = nullptr) {
   __shared__ T thc[(MAXN + 1) * MAXN];  // later reused as th[i][class bit l]
-  __shared__ T rsplit[(MAXN + 1) * 192];  // [i][three 6-bit parts of S] partial rate products (row N: observation)
+  // [i][three 6-bit parts of S] partial rate products (row N: observation): (N + 1) * 192 elements of dynamic LDS (prep_lds) - sized
+  // by the engine's N, not by MAXN: 42 instead of 59 KB at N = 21, three workgroups per CU instead of two
+  extern __shared__ __align__(16) unsigned char prep_smem[];
+  T* const rsplit = reinterpret_cast<T*>(prep_smem);
   __shared__ Desc d;
   load_desc(&d, descs + (plist ? plist[blockIdx.x] : (int)blockIdx.x));   // (plist: only these problems of the list)
   __syncthreads();
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
   const int part = SPLIT ? (int)(blockIdx.y >> 2) : 0, nparts = SPLIT ? (int)(gridDim.y >> 2) : 1;   // a long table: S dealt over parts
   if (job == 3 && part > 0) return;
   if (job < 0 || job == 3) {
-  for (int e = tid; e < k * k; e += BLOCK) {
+  for (int e = tid; e < k * k; e += PB) {
     const int b = e / k, bb = e % k;
     const int row = d.ev[b], c = d.cls[b];
     const int pc = c == CS ? CP : c;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
   }
   __syncthreads();
   const int nl = k < 6 ? k : 6;
-  for (int e = tid; e < k * 64; e += BLOCK) {
+  for (int e = tid; e < k * 64; e += PB) {
     const int b = e >> 6, l = e & 63;
     T v = 1, u = 1;
     for (int bb = 0; bb < nl; ++bb) if (bb != b && ((l >> bb) & 1)) v *= thc[b * k + bb];
@@ -138,10 +145,10 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     const uint32_t cm = c == 0 ? d.maskP : c == 1 ? d.maskM : d.pairP;
     const int kc = __popc(cm);
     if (job >= 0 && c != job) { o += 1ll << kc; continue; }
-    if ((long long)part * BLOCK >= (1ll << kc)) return;        // (uniform: nothing of this table falls to this part)
+    if ((long long)part * PB >= (1ll << kc)) return;        // (uniform: nothing of this table falls to this part)
     __syncthreads();
     // th[i][l] = theta[i][event of the l-th class bit]
-    for (int e = tid; e < N * kc; e += BLOCK) {
+    for (int e = tid; e < N * kc; e += PB) {
       const int i = e / kc, l = e % kc;
       uint32_t m = cm;
       for (int q = 0; q < l; ++q) m &= m - 1;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     __syncthreads();
     const T* dv = c == 1 ? P.dm : P.dp;
     // row N of the table: the observation factors dvec[event of bit l]
-    for (int l = tid; l < kc; l += BLOCK) {
+    for (int l = tid; l < kc; l += PB) {
       uint32_t m = cm;
       for (int q = 0; q < l; ++q) m &= m - 1;
       thc[N * kc + l] = dv[d.ev[__ffs(m) - 1]];
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
     const bool split = kc <= 18;
     const int np6 = !SPLIT ? 3 : kc <= 6 ? 1 : kc <= 12 ? 2 : 3;   // 6-bit parts in use (SPLIT: the others are left out)
     if (split) {
-      for (int e = tid; e < (N + 1) * 192; e += BLOCK) {
+      for (int e = tid; e < (N + 1) * 192; e += PB) {
         const int i = e / 192, part = (e % 192) >> 6, v = e & 63;
         if (part >= np6) continue;
         T r = 1;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) void k_prep(const Desc* __restrict__ descs,
       }
       __syncthreads();
     }
-    for (long long S = tid + (long long)part * BLOCK; S < (1ll << kc); S += (long long)BLOCK * nparts) {
+    for (long long S = tid + (long long)part * PB; S < (1ll << kc); S += (long long)PB * nparts) {
       const int s0 = (int)(S & 63), s1 = (int)((S >> 6) & 63), s2 = (int)(S >> 12);
       T obs = c == 0 ? P.dp[n] : c == 1 ? P.dm[n] : T(1);
       if (split) { T m = rsplit[N * 192 + s0]; if (np6 > 1) m *= rsplit[N * 192 + 64 + s1]; if (np6 > 2) m *= rsplit[N * 192 + 128 + s2]; obs *= m; }

@@ -703,8 +703,9 @@ struct Engine : EngineBase {
     // SPLIT: a table of more than 2^9 entries is dealt over several workgroups (the launch is the head of every evaluation
     // of a short cohort; at most 32 parts: the workgroups of the shorter tables of the launch exit at once, but they are launched)
     const int parts = maxkc > 9 ? 1 << std::min(maxkc - 9, 5) : 1;
-    if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4 * parts), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
-    else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), 0, stream, descs, d_par.p, tab);
+    if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4 * parts), dim3(BLOCK), prep_lds<T>(N), stream, descs, d_par.p, tab);
+    else if (nprob >= 1024) hipLaunchKernelGGL((k_prep<T, false, 1024>), dim3(nprob), dim3(1024), prep_lds<T>(N), stream, descs, d_par.p, tab);
+    else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), prep_lds<T>(N), stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
   }
 
@@ -1501,7 +1502,7 @@ struct Engine : EngineBase {
         // (the group's accumulators cleared, the e_0 right-hand sides written: before anything of the group runs)
         hipLaunchKernelGGL((k_staged_init<T>), dim3(nG), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dS.p, rhsS.p, GS.p, bmS.p, N, grad ? 1 : 0, g.d_pats.p);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), 0, stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
+        hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), prep_lds<T>(N), stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
         HIPCHECK(hipGetLastError());
         // marginal right-hand sides (the small-space kernels read pi themselves and write the links)
         if (!g.paired.empty()) {
