@@ -80,6 +80,12 @@ __device__ __forceinline__ void wave_bit_sums(T v, int lane, int nb, T& total, T
   if (nb > 5) M[5] = lane63(dpp_stages_from<5>((lane & 32) ? p5 : T(0)));
 }
 
+// value of lane `src` (a compile-time or wave-uniform index) in every lane
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
 // grid = (work list of (problem, subset chunk), ceil(N / WAVES)); wave w owns event i = blockIdx.y * WAVES + w
 // and strides the subsets S across its lanes; all reductions are wave-level.
 constexpr int GR_CHUNK = 11;                      // subsets per workgroup of k_grad_rows: 2^11
@@ -111,9 +117,10 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
   if (kind == GK_P) cm = d.maskP; else if (kind == GK_M) cm = d.maskM;
   else if (kind == GK_E) cm = d.pairP; else cm = (1u << d.k) - 1u;
   const int kc = __popc(cm);
-  if (tid == 0) {
-    uint32_t m = cm; int l = 0;
-    while (m) { const int b = __ffs(m) - 1; lev[l] = d.ev[b]; ++l; m &= m - 1; }
+  if (tid < kc) {                               // (lane l: the l-th bit of the class - one global read each, side by side)
+    uint32_t m = cm;
+    for (int q = 0; q < tid; ++q) m &= m - 1;
+    lev[tid] = d.ev[__ffs(m) - 1];
   }
   __syncthreads();
   // row N (joint kinds only): observation-rate gradient from the same marginals,
@@ -140,12 +147,16 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
     const int klo = kc < 6 ? kc : 6;
     const int kin = kc < GR_CHUNK ? kc : GR_CHUNK;   // subset bits that vary inside this workgroup's chunk
     const int nhi = kin - klo;
+    // (the factor of class bit l sits in lane l: one global read per lane, the products below take them out of registers)
+    const T fl = lane < kc ? fvec[lev[lane < kc ? lane : 0]] : T(1);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {          // one table per 6-bit part of the subset index
       T v = 1;
+#pragma unroll
       for (int l = 0; l < 6; ++l) {
         const int ll = part * 6 + l;
-        if (ll < kc && ((lane >> l) & 1)) v *= fvec[lev[ll]];
+        const T f = lane_bcast(fl, ll);
+        if (ll < kc && ((lane >> l) & 1)) v *= f;
       }
       Tlo[w * 192 + part * 64 + lane] = v;
     }
