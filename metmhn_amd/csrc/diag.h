@@ -18,8 +18,9 @@ namespace mmhn {
 // ------------------------------------------------------------------------------------
 enum { KD_DQ = 0, KD_LIDG = 1, KD_ADDQP = 2, KD_DP = 3, KD_DM = 4, KD_QP = 5, KD_SDP = 6 };
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
+// KB: threads of a workgroup (1 024 on long launches: three workgroups per CU hold the LDS either way - 48 instead of 12 waves)
+template <typename T, int KB = BLOCK>
+__global__ __launch_bounds__(KB) void k_diag(const Desc* __restrict__ descs,
                                                 const int2* __restrict__ map,
                                                 const Params<T>* __restrict__ par,
                                                 const T* __restrict__ p, T* out,
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
   const bool joint = d.mode == JOINT;
   const int nl = k < 6 ? k : 6;
 
-  for (int e = tid; e < N * 64; e += BLOCK) {
+  for (int e = tid; e < N * 64; e += KB) {
     const int i = e >> 6, l = e & 63;
     T vP = 1, vM = 1;
     for (int bb = 0; bb < nl; ++bb)
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(BLOCK) void k_diag(const Desc* __restrict__ descs,
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
-  for (int r = wave; r < R; r += WAVES) {
+  for (int r = wave; r < R; r += KB / 64) {
     const uint32_t xl = ((uint32_t)r << 6) | (uint32_t)lane;
     if (xl >= nelem) continue;
     const uint32_t x = (H << t) | xl;

@@ -704,7 +704,7 @@ struct Engine : EngineBase {
     // of a short cohort; at most 32 parts: the workgroups of the shorter tables of the launch exit at once, but they are launched)
     const int parts = maxkc > 9 ? 1 << std::min(maxkc - 9, 5) : 1;
     if (joint && nprob <= prep_split_max) hipLaunchKernelGGL((k_prep<T, true>), dim3(nprob, 4 * parts), dim3(BLOCK), prep_lds<T>(N), stream, descs, d_par.p, tab);
-    else if (nprob >= 1024) hipLaunchKernelGGL((k_prep<T, false, 1024>), dim3(nprob), dim3(1024), prep_lds<T>(N), stream, descs, d_par.p, tab);
+    else if (nprob >= 256) hipLaunchKernelGGL((k_prep<T, false, 1024>), dim3(nprob), dim3(1024), prep_lds<T>(N), stream, descs, d_par.p, tab);
     else hipLaunchKernelGGL((k_prep<T, false>), dim3(nprob), dim3(BLOCK), prep_lds<T>(N), stream, descs, d_par.p, tab);
     HIPCHECK(hipGetLastError());
   }
@@ -773,8 +773,11 @@ struct Engine : EngineBase {
                    int pbit = -1) {
     if (ntiles == 0) return;
     const size_t lds = DESC_PAD + ((size_t)4 * N * 64 + 256) * sizeof(T);
-    hipLaunchKernelGGL((k_diag<T>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, outp, dvec,
-                       what, N, pbit);
+    if (ntiles >= 256)
+      hipLaunchKernelGGL((k_diag<T, 1024>), dim3(ntiles), dim3(1024), lds, stream, descs, map, d_par.p, p, outp, dvec, what, N, pbit);
+    else
+      hipLaunchKernelGGL((k_diag<T>), dim3(ntiles), dim3(BLOCK), lds, stream, descs, map, d_par.p, p, outp, dvec,
+                         what, N, pbit);
     HIPCHECK(hipGetLastError());
   }
   // dj != nullptr (joint kinds): one extra row per problem with the observation-rate gradient
@@ -1502,7 +1505,10 @@ struct Engine : EngineBase {
         // (the group's accumulators cleared, the e_0 right-hand sides written: before anything of the group runs)
         hipLaunchKernelGGL((k_staged_init<T>), dim3(nG), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dS.p, rhsS.p, GS.p, bmS.p, N, grad ? 1 : 0, g.d_pats.p);
         HIPCHECK(hipGetLastError());
-        hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), prep_lds<T>(N), stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
+        if (g.probs.size() >= 256)
+          hipLaunchKernelGGL((k_prep<T, false, 1024>), dim3((unsigned)g.probs.size()), dim3(1024), prep_lds<T>(N), stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
+        else
+          hipLaunchKernelGGL((k_prep<T, false>), dim3((unsigned)g.probs.size()), dim3(BLOCK), prep_lds<T>(N), stream, b.d_dS.p, d_par.p, tabS.p, g.d_probs.p);
         HIPCHECK(hipGetLastError());
         // marginal right-hand sides (the small-space kernels read pi themselves and write the links)
         if (!g.paired.empty()) {
