@@ -1594,6 +1594,10 @@ struct Engine : EngineBase {
           // 5 joint adjoint: right-hand side D_obs * scatter(q_S) formed on the fly inside the solve
           if (use_jacobi) zero(rhsJ.p, b.vecJ);
           for (int part = 0; part < 2 && !b.stg[1].paired.empty(); ++part) {
+            if (b.stg[1].paired.size() >= 256)
+              hipLaunchKernelGGL((k_scatter_marg<T, 1024>), dim3((unsigned)b.stg[1].paired.size()), dim3(1024), 0, stream, b.d_pats.p, b.d_dJ.p,
+                                 b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part, b.stg[1].d_paired.p);
+            else
             hipLaunchKernelGGL((k_scatter_marg<T>), dim3((unsigned)b.stg[1].paired.size()), dim3(BLOCK), 0, stream, b.d_pats.p, b.d_dJ.p,
                                b.d_dS.p, d_par.p, qS.p, rhsS.p, use_jacobi ? rhsJ.p : nullptr, dots.p, part, b.stg[1].d_paired.p);
             HIPCHECK(hipGetLastError());

@@ -59,15 +59,16 @@ __global__ __launch_bounds__(BLOCK) void k_gather_marg(const PatRec* __restrict_
 
 // rhsJ[compatible] += D * qS[upper half];  dots[pat][part] = <qS upper half, rhsS upper half>
 // one workgroup per patient; launched once per part (the two parts share the all-ones state)
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict__ pats,
+// KB: threads of a workgroup (1 024 on long launches: a patient's marginal space of up to 2^16 states is one workgroup's loop)
+template <typename T, int KB = BLOCK>
+__global__ __launch_bounds__(KB) void k_scatter_marg(const PatRec* __restrict__ pats,
                                                         const Desc* __restrict__ dJ,
                                                         const Desc* __restrict__ dS,
                                                         const Params<T>* __restrict__ par,
                                                         const T* __restrict__ qS,
                                                         const T* __restrict__ rhsS, T* rhsJ,
                                                         T* dots, int part, const int* __restrict__ plist) {
-  __shared__ T red[BLOCK];
+  __shared__ T red[KB];
   const int pat = plist ? plist[blockIdx.x] : (int)blockIdx.x;     // (plist: the patients on the staged kernels)
   const PatRec pr = pats[pat];
   if (pr.j < 0 || pr.s[part] < 0) return;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
   const uint32_t half = 1u << (ds.k - 1);
   const T c = obs_const(dj, par[PS_THETA], part);
   T dot = 0;
-  for (uint32_t e = threadIdx.x; e < half; e += BLOCK) {
+  for (uint32_t e = threadIdx.x; e < half; e += KB) {
     const uint32_t x = pdep32(e, free_) | fixed;
     const T qv = qS[ds.off + half + e];
     if (rhsJ) rhsJ[dj.off + x] += c * qv;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter_marg(const PatRec* __restrict
   }
   red[threadIdx.x] = dot;
   __syncthreads();
-  for (int s = BLOCK / 2; s > 0; s >>= 1) {
+  for (int s = KB / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
