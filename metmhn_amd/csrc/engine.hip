@@ -798,8 +798,17 @@ struct Engine : EngineBase {
                         const DevArr<int2>& chunks, T* dj = nullptr, long long gstride = 0) {
     if (nprob == 0 || chunks.n == 0) return;
     (void)maxk;
-    const size_t lds = ((size_t)WAVES * 192 + WAVES * 32) * sizeof(T);
     const int rows = N + (dj ? 1 : 0);
+    if (chunks.n >= 1024) {
+      // long launches: one row (wave) per workgroup - no barrier, nothing shared but the class-bit list (measured on the bench cohort,
+      // rows per workgroup 1 / 2 / 4 / 8 / 12: the step minus its big kernels 4.08 / 4.12 / 4.16 / 4.45 / 4.62 ms)
+      const size_t lds1 = ((size_t)192 + 32) * sizeof(T);
+      hipLaunchKernelGGL((k_grad_rows<T, 1>), dim3((unsigned)chunks.n, rows), dim3(64), lds1, stream,
+                         descs, d_par.p, A, p, q, G, kind, dj, chunks.p, nprob, gstride);
+      HIPCHECK(hipGetLastError());
+      return;
+    }
+    const size_t lds = ((size_t)WAVES * 192 + WAVES * 32) * sizeof(T);
     hipLaunchKernelGGL((k_grad_rows<T>), dim3((unsigned)chunks.n, (rows + WAVES - 1) / WAVES), dim3(BLOCK), lds, stream,
                        descs, d_par.p, A, p, q, G, kind, dj, chunks.p, nprob, gstride);
     HIPCHECK(hipGetLastError());

@@ -90,8 +90,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_
 // and strides the subsets S across its lanes; all reductions are wave-level.
 constexpr int GR_CHUNK = 11;                      // subsets per workgroup of k_grad_rows: 2^11
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ descs,
+// GW: waves (= rows) of a workgroup: 4, or 1 on long launches (engine.hip: launch_grad_rows)
+template <typename T, int GW = WAVES>
+__global__ __launch_bounds__(GW * 64) void k_grad_rows(const Desc* __restrict__ descs,
                                                      const Params<T>* __restrict__ par,
                                                      const T* __restrict__ A,
                                                      const T* __restrict__ p,
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
                                                      int nprob, long long gstride) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Tlo = reinterpret_cast<T*>(smem);          // [WAVES][3][64]: rate products over subset bits 0-5, 6-11, 12-17
-  T* rowbuf = Tlo + WAVES * 192;                // [WAVES][32]
+  T* rowbuf = Tlo + GW * 192;                   // [GW][32]
   __shared__ int lev[32];                       // event of local bit l
   // (problem, subset chunk) work list; kind_arg < 0: the kind rides in bits 24+ of the chunk field and selects the G matrix
   const int prob = chunks[blockIdx.x].x;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_rows(const Desc* __restrict__ de
   const Desc& d = descs[prob];
   const int N = d.N, n = N - 1;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const int i = blockIdx.y * WAVES + w;
+  const int i = blockIdx.y * GW + w;
   const Params<T>& P = par[d.pset];
 
   uint32_t cm;
