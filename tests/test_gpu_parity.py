@@ -1117,6 +1117,44 @@ def _one_rank_comm(e):
 
 
 @pytest.mark.gpu
+def test_long_launches_at_the_largest_event_count():
+    """The 1 024-thread instantiations the long launches take (k_prep, k_diag, k_scatter_marg; one-row k_grad_rows) at n = 30 events
+    - the dynamic LDS of k_prep / k_diag grows with the event count (N = 31: 49 / 65 KB, above the default window) - on 320 unpaired
+    rows with 13 - 14 active events (single-tumour spaces of four tiles: the staged kernels, more than 256 problems and tiles in every
+    launch) and 300 paired rows with small joint spaces; log-probabilities and gradients against oracle/metmhn_ref.c."""
+    from oracle import cref
+    from metmhn_amd import Engine, synthetic
+    n = 30
+    lt, dp, dm = synthetic.random_params(n, seed=31)
+    rng = np.random.default_rng(77)
+    rows = []
+    for r in range(320):
+        bits = np.zeros(2 * n, dtype=np.int8)
+        ev = rng.choice(n, size=13 + (r & 1), replace=False)
+        typ = r % 3
+        if typ == 2:
+            bits[2 * ev + 1] = 1
+            rows.append(np.concatenate((bits, [1, -99, 2])))
+        else:
+            bits[2 * ev] = 1
+            rows.append(np.concatenate((bits, [typ, -99, typ])))
+    for r in range(300):
+        bits = np.zeros(2 * n, dtype=np.int8)
+        bits[rng.choice(2 * n, size=int(rng.integers(2, 9)), replace=False)] = 1
+        rows.append(np.concatenate((bits, [1, int(rng.integers(0, 3)), 3])))
+    dat = np.array(rows, dtype=np.int8)
+    lp, g, a, b = cref.patients(lt, dp, dm, dat, with_grad=True)
+    e = Engine(n)
+    e.set_cohort(dat)
+    r = e.patient_grads(lt, dp, dm)
+    e.close()
+    np.testing.assert_allclose(r[0], lp, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(r[1], g, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[2], a, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r[3], b, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_full_size_gradient_is_directional_difference_of_score():
     """The reference's own test strategy (tests/test_gradient.py:9-31,68-69: analytic gradient of score_and_grad against finite
     differences of score) at the headline size, where no oracle finishes in seconds: 320 paired patients with n = k = 20 of every
